@@ -1,0 +1,193 @@
+/*
+ * kmc.h -- C ABI of the MI355X k-mer counter (libkmc.so).
+ *
+ * This is the drop-in boundary for the reference's hot path.  The reference
+ * (jaxonwang/k-mer-count @ v1, paths below relative to /root/reference) has no FFI of its own:
+ * its whole pipeline is one function, k-mer-count/src/main.rs:43-91.  The entry points below
+ * are what a Rust `extern "C"` block in that crate would bind so that main() keeps FASTA
+ * reading (main.rs:44-46,58-62) and printing (main.rs:88-90) and hands the loop nest in
+ * between (main.rs:63-87) to the GPU.  INTEGRATION.md shows the binding.
+ *
+ *   reference code being replaced                         entry point
+ *   ----------------------------------------------------  ---------------------------------
+ *   constants l_len/r_len/80..141, main.rs:48-49,63       kmc_create(kmc_config)
+ *   per-record window loop + push, main.rs:58-81          kmc_add_batch / kmc_add_batch_device
+ *   radix_sort + sort (grouping), main.rs:84,87           kmc_finalize
+ *   iteration over the sorted result, main.rs:88-90       kmc_export (sorted ascending)
+ *   File::open + Reader + loop, main.rs:44-46,58-62       kmc_count_file (convenience; host parser)
+ *   random_fasta_generator.py:5-15                        kmc_synth_* (seeded, sized re-creation)
+ *
+ * Conventions
+ *   - Every function returns 0 (KMC_OK) or a negative kmc_status; no exception or abort crosses
+ *     the ABI (the reference panics instead: main.rs:23,35,44,59).
+ *   - Alphabet A=0 C=1 G=2 T=3 (main.rs:19-22); keys are packed MSB-first so unsigned order of
+ *     (key_hi,key_lo) equals the reference's string order (main.rs:87).  key_hi is 0 for k<=32.
+ *   - The caller owns every host buffer passed in or out; buffers passed to kmc_add_batch may be
+ *     reused as soon as it returns.  The library owns the ctx and all device memory.
+ *   - A ctx is bound to ONE GPU and is not thread-safe; distinct ctxs are independent.
+ *   - There is NO CPU fallback: if no HIP device is usable kmc_create fails with
+ *     KMC_ERR_NO_DEVICE.
+ */
+#ifndef KMC_H
+#define KMC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMC_VERSION_MAJOR 0
+#define KMC_VERSION_MINOR 1
+
+typedef enum kmc_status {
+    KMC_OK = 0,
+    KMC_ERR_ARG = -1,        /* bad argument / unsupported k */
+    KMC_ERR_NO_DEVICE = -2,  /* no usable HIP device (no CPU fallback exists) */
+    KMC_ERR_HIP = -3,        /* a HIP runtime call failed; see kmc_last_error */
+    KMC_ERR_NOMEM = -4,      /* host or device allocation failed */
+    KMC_ERR_IO = -5,         /* cannot open/read file            (main.rs:44) */
+    KMC_ERR_FORMAT = -6,     /* "Expected > at record start."    (main.rs:59) */
+    KMC_ERR_ALPHABET = -7,   /* non-ACGT byte in LR mode         (main.rs:23) */
+    KMC_ERR_CAPACITY = -8,   /* count table and spill area exhausted */
+    KMC_ERR_STATE = -9       /* call out of order (e.g. export before finalize) */
+} kmc_status;
+
+typedef enum kmc_mode {
+    KMC_MODE_CONTIG = 0, /* contiguous k-mers, SURVEY.md 8a-def */
+    KMC_MODE_LR = 1      /* reference mode: 27 + gap + 27, chunk sizes 80..=140 (main.rs:48-49,63) */
+} kmc_mode;
+
+typedef enum kmc_algo {
+    KMC_ALGO_AUTO = 0,   /* pick per batch */
+    KMC_ALGO_STREAM = 1, /* per-k-mer LDS partial histogram + global atomics (any input) */
+    KMC_ALGO_WALK = 2    /* memoised successor walk: one LDS lookup per 8 bases (short reads) */
+} kmc_algo;
+
+typedef struct kmc_config {
+    uint32_t struct_size;   /* = sizeof(kmc_config) */
+    int32_t  k;             /* 1..63 in KMC_MODE_CONTIG; ignored in KMC_MODE_LR */
+    int32_t  mode;          /* kmc_mode */
+    int32_t  canonical;     /* 1: key = min(fwd, revcomp); 0: forward strand (the reference is forward-only) */
+    int32_t  device;        /* HIP device ordinal */
+    int32_t  algo;          /* kmc_algo */
+    uint64_t capacity_hint; /* expected distinct keys; 0 = default.  The table grows between batches. */
+    void*    stream;        /* hipStream_t to run on, or NULL for a ctx-owned stream */
+} kmc_config;
+
+typedef struct kmc_ctx kmc_ctx;
+
+/* Per-ctx counters, all cumulative since kmc_create / kmc_reset. */
+typedef struct kmc_stats {
+    uint64_t n_reads;
+    uint64_t n_bases;
+    uint64_t n_kmers;         /* valid windows counted (== sum of counts) */
+    uint64_t n_distinct;      /* valid after kmc_finalize */
+    uint64_t table_capacity;  /* slots */
+    uint64_t n_spilled;       /* pairs that went through the spill area */
+    uint64_t n_batches;
+    double   kernel_ms_last;  /* hipEvent time of the count kernel(s) of the last batch */
+    double   kernel_ms_total;
+    int32_t  algo_last;       /* kmc_algo actually used for the last batch */
+    int32_t  reserved;
+} kmc_stats;
+
+const char* kmc_version(void);
+const char* kmc_status_string(int status);
+
+int  kmc_create(kmc_ctx** out, const kmc_config* cfg);
+void kmc_destroy(kmc_ctx* ctx);
+/* Message of the last failing call on this ctx (owned by the ctx; "" if none).  ctx may be NULL:
+ * then the message of the last failing kmc_create on this thread. */
+const char* kmc_last_error(const kmc_ctx* ctx);
+
+/* Forget all counts (table kept allocated). */
+int kmc_reset(kmc_ctx* ctx);
+
+/* Count one batch of reads.  `bases`: ASCII bases of all reads concatenated (no newlines);
+ * `offsets[n_reads+1]`: start of each read, offsets[0] == 0, offsets[n_reads] == total bases.
+ * Host buffers; copied to the device before return. */
+int kmc_add_batch(kmc_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads);
+
+/* Same, for buffers already resident in this ctx's GPU memory (HBM-resident timing, pipelines
+ * that parse into pinned/device memory).  d_bases must be 16-byte aligned and readable up to the
+ * next 16-byte boundary past the last base.  max_read_len: longest read in the batch, or 0 if
+ * unknown (then it is computed on the device).  Asynchronous on the ctx stream. */
+int kmc_add_batch_device(kmc_ctx* ctx, const void* d_bases, const void* d_offsets,
+                         uint64_t n_reads, uint64_t n_bases, uint64_t max_read_len);
+
+/* Merge (key,count) pairs that already live on this GPU into the table (multi-GPU reduce:
+ * pairs received from a peer over RCCL).  d_key_hi may be NULL when k <= 32 / not LR. */
+int kmc_merge_pairs_device(kmc_ctx* ctx, const void* d_key_hi, const void* d_key_lo,
+                           const void* d_count, uint64_t n_pairs);
+
+/* Compact the table, sort by key on the device, report sizes.  May be called repeatedly;
+ * more batches may be added afterwards (the sorted view is then stale until the next finalize). */
+int kmc_finalize(kmc_ctx* ctx, uint64_t* n_distinct, uint64_t* n_total);
+
+/* Copy the sorted table to caller-allocated host arrays of `cap` entries (cap >= n_distinct).
+ * key_hi may be NULL if the caller knows k <= 32. */
+int kmc_export(kmc_ctx* ctx, uint64_t* key_hi, uint64_t* key_lo, uint64_t* count, uint64_t cap);
+
+/* Device pointers to the sorted table of the last kmc_finalize (owned by the ctx, valid until the
+ * next finalize/reset/destroy).  d_key_hi is NULL when keys fit one word. */
+int kmc_export_device(kmc_ctx* ctx, const void** d_key_hi, const void** d_key_lo,
+                      const void** d_count, uint64_t* n_distinct);
+
+/* Owner-partitioned view for an all-to-all exchange: after kmc_finalize, reorders the sorted
+ * table so that pairs with owner(key) == p are contiguous, p = 0..n_parts-1, where
+ * owner = mix(key) % n_parts (kmc_owner_of gives the same function on the host).
+ * part_begin[n_parts+1] (host) receives the boundaries.  Pointers as in kmc_export_device. */
+int kmc_partition_device(kmc_ctx* ctx, uint32_t n_parts, uint64_t* part_begin,
+                         const void** d_key_hi, const void** d_key_lo, const void** d_count);
+uint32_t kmc_owner_of(uint64_t key_hi, uint64_t key_lo, uint32_t n_parts);
+
+int kmc_get_stats(const kmc_ctx* ctx, kmc_stats* out);
+
+/* Convenience used by the CLI: parse `path` on the host (restating the reader the reference
+ * uses, main.rs:45-46,59-62), feed batches, finalize.  Results via kmc_export. */
+int kmc_count_file(kmc_ctx* ctx, const char* path, uint64_t* n_distinct, uint64_t* n_total);
+
+/* Host FASTA reader on its own (library-owned buffers; free with kmc_free_reads). */
+typedef struct kmc_reads {
+    uint8_t*  bases;
+    uint64_t* offsets;
+    uint64_t  n_reads;
+    uint64_t  n_bases;
+    uint64_t  max_read_len;
+} kmc_reads;
+int  kmc_parse_fasta(const char* path, kmc_reads* out, char* errbuf, size_t errbuf_len);
+void kmc_free_reads(kmc_reads* r);
+
+/* Decode a key into klen ASCII characters (no terminator). */
+void kmc_decode_key(uint64_t key_hi, uint64_t key_lo, int klen, char* out);
+
+/* ---- synthetic input: seeded, size-parameterised re-creation of the distribution of
+ * random_fasta_generator.py:5-15 (pool of `pool` random lines of `line_len` bases; each record
+ * = `lines_per_record` lines drawn uniformly from the pool; pool == 0: every line fresh random).
+ * Counter-based PRNG, so any record range can be generated independently and identically on
+ * host and device. ---- */
+typedef struct kmc_synth {
+    uint64_t seed;
+    uint32_t pool;             /* 10 in the reference (:5) */
+    uint32_t line_len;         /* 80 (:6) */
+    uint32_t lines_per_record; /* 5 (:13) */
+    uint32_t reserved;
+} kmc_synth;
+
+/* Number of records whose FASTA text (header ">dummy_sequence_NNN Nth record\n", :11-12, plus
+ * lines) first reaches `file_bytes` bytes; also the exact byte size of that text. */
+uint64_t kmc_synth_records_for_bytes(const kmc_synth* s, uint64_t file_bytes, uint64_t* exact_bytes);
+/* Parsed form of records [first, first+n): bases (n*lines*line_len bytes) and offsets[n+1]. */
+int kmc_synth_reads_host(const kmc_synth* s, uint64_t first_record, uint64_t n_records,
+                         uint8_t* bases, uint64_t* offsets);
+int kmc_synth_reads_device(const kmc_synth* s, uint64_t first_record, uint64_t n_records,
+                           void* d_bases, void* d_offsets, int device, void* stream);
+/* FASTA text of records [first, first+n) appended to `FILE_ptr` (a FILE*). */
+int kmc_synth_write_fasta(const kmc_synth* s, uint64_t first_record, uint64_t n_records, void* FILE_ptr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMC_H */

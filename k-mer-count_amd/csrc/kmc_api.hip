@@ -1,0 +1,705 @@
+// kmc_api.hip -- the C ABI of libkmc.so (include/kmc.h): context management, batch
+// scheduling, table growth, finalisation (compact + device radix sort), export.
+//
+// One ctx == one GPU.  All work is queued on the ctx stream; kernels are the hand-written
+// gfx950 kernels of kmc_stream.cuh / kmc_walk.cuh / kmc_table.cuh.  There is no CPU path: if
+// the HIP runtime has no device, kmc_create fails.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <cstring>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/kmc.h"
+#include "kmc_device.cuh"
+#include "kmc_stream.cuh"
+#include "kmc_synth.cuh"
+#include "kmc_table.cuh"
+#include "kmc_walk.cuh"
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Table {
+    u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr;
+    u64 cap = 0;
+};
+
+}  // namespace
+
+struct kmc_ctx {
+    kmc_config cfg{};
+    int KW = 1;     // key words
+    int klen = 0;   // characters per key (k, or 54 in LR mode)
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    Table tab;
+    u64* d_counters = nullptr;      // KMC_CTR_N u64
+    u64* h_counters = nullptr;      // pinned mirror
+    u64 *spill_hi = nullptr, *spill_lo = nullptr, *spill_cnt = nullptr;
+    u64 spill_cap = 0;
+
+    // staging for host batches
+    DevBuf st_bases, st_offsets;
+    // sorted view
+    DevBuf o_hi, o_lo, o_cnt, t_hi, t_lo, t_cnt, t_idx0, t_idx1, t_key, sort_tmp, p_hi, p_lo, p_cnt;
+    u64 n_sorted = 0;
+    bool sorted_valid = false;
+    // walk-kernel workspace
+    DevBuf walk_ws;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    kmc_stats st{};
+    bool pending = false;  // a batch has been queued since the last counter poll
+    double rho_max = 0.0;  // largest observed (new distinct) / (k-mers) over a sub-batch
+    int n_cu = 256;
+};
+
+namespace {
+
+int fail(kmc_ctx* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                       \
+    do {                                                                                      \
+        hipError_t e__ = (call);                                                              \
+        if (e__ != hipSuccess)                                                                \
+            return fail((c), e__ == hipErrorOutOfMemory ? KMC_ERR_NOMEM : KMC_ERR_HIP, "%s: %s", #call, hipGetErrorString(e__)); \
+    } while (0)
+
+int ensure(kmc_ctx* c, DevBuf& b, size_t bytes) {
+    if (b.bytes >= bytes && b.p) return KMC_OK;
+    if (b.p) { HIPCHK(c, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(c, hipMalloc(&b.p, want));
+    b.bytes = want;
+    return KMC_OK;
+}
+
+void free_buf(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+void free_table(Table& t) {
+    if (t.hi) (void)hipFree(t.hi);
+    if (t.lo) (void)hipFree(t.lo);
+    if (t.cnt) (void)hipFree(t.cnt);
+    t = Table{};
+}
+
+int alloc_table(kmc_ctx* c, Table& t, u64 cap) {
+    t = Table{};
+    t.cap = cap;
+    HIPCHK(c, hipMalloc((void**)&t.lo, cap * sizeof(u64)));
+    HIPCHK(c, hipMalloc((void**)&t.cnt, cap * sizeof(u64)));
+    if (c->KW == 2) HIPCHK(c, hipMalloc((void**)&t.hi, cap * sizeof(u64)));
+    // EMPTY marker is all ones in the word that is CASed
+    if (c->KW == 2) {
+        HIPCHK(c, hipMemsetAsync(t.hi, 0xFF, cap * sizeof(u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(t.lo, 0, cap * sizeof(u64), c->stream));
+    } else {
+        HIPCHK(c, hipMemsetAsync(t.lo, 0xFF, cap * sizeof(u64), c->stream));
+    }
+    HIPCHK(c, hipMemsetAsync(t.cnt, 0, cap * sizeof(u64), c->stream));
+    return KMC_OK;
+}
+
+GTable gtable_of(const kmc_ctx* c, const Table& t) {
+    GTable g;
+    g.key_hi = t.hi;
+    g.key_lo = t.lo;
+    g.count = t.cnt;
+    g.capmask = t.cap - 1;
+    g.counters = c->d_counters;
+    g.spill_hi = c->spill_hi;
+    g.spill_lo = c->spill_lo;
+    g.spill_cnt = c->spill_cnt;
+    g.spill_cap = c->spill_cap;
+    return g;
+}
+
+u64 next_pow2(u64 v) {
+    u64 p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+int grid_for(const kmc_ctx* c, u64 n, int threads) {
+    u64 blocks = (n + threads - 1) / threads;
+    u64 cap = (u64)c->n_cu * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+template <typename F1, typename F2>
+auto kw_dispatch(int KW, F1 f1, F2 f2) { return KW == 1 ? f1() : f2(); }
+
+// read the device counters (synchronises the stream)
+int poll(kmc_ctx* c) {
+    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, KMC_CTR_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pending = false;
+    return KMC_OK;
+}
+
+int grow_to(kmc_ctx* c, u64 newcap) {
+    Table nt;
+    int rc = alloc_table(c, nt, newcap);
+    if (rc) { free_table(nt); return rc; }
+    // fresh occupancy count: rehash re-counts every claimed slot
+    HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_OCCUPIED], 0, sizeof(u64), c->stream));
+    GTable go = gtable_of(c, c->tab), gn = gtable_of(c, nt);
+    int grid = grid_for(c, c->tab.cap, 256);
+    if (c->KW == 1) hipLaunchKernelGGL(kmc_rehash_kernel<1>, dim3(grid), dim3(256), 0, c->stream, go, gn);
+    else hipLaunchKernelGGL(kmc_rehash_kernel<2>, dim3(grid), dim3(256), 0, c->stream, go, gn);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_table(c->tab);
+    c->tab = nt;
+    c->st.table_capacity = newcap;
+    return KMC_OK;
+}
+
+// Called with fresh h_counters: drain the spill area and grow when the table is over half full.
+int settle(kmc_ctx* c) {
+    for (int iter = 0; iter < 40; ++iter) {
+        u64 occ = c->h_counters[KMC_CTR_OCCUPIED], spill = c->h_counters[KMC_CTR_SPILL], err = c->h_counters[KMC_CTR_ERR];
+        if (err) return fail(c, KMC_ERR_CAPACITY, "count table and spill area exhausted (capacity %llu slots, %llu spilled); raise capacity_hint",
+                             (unsigned long long)c->tab.cap, (unsigned long long)spill);
+        if (!spill && occ * 2 <= c->tab.cap) return KMC_OK;
+        u64 need = (occ + spill) * 2;
+        u64 newcap = c->tab.cap;
+        while (newcap < need) newcap <<= 1;
+        if (newcap == c->tab.cap && spill) newcap <<= 1;
+        if (newcap != c->tab.cap) {
+            int rc = grow_to(c, newcap);
+            if (rc) return rc;
+        }
+        if (spill) {
+            // move the spill entries aside conceptually: merge them, then clear the counter
+            u64 n = spill;
+            c->st.n_spilled += n;
+            GTable g = gtable_of(c, c->tab);
+            // the merge may itself spill (appends after position n); handled by the next iteration
+            u64 *sh = nullptr, *sl = nullptr, *sc = nullptr;
+            HIPCHK(c, hipMalloc((void**)&sl, n * sizeof(u64)));
+            HIPCHK(c, hipMalloc((void**)&sc, n * sizeof(u64)));
+            if (c->KW == 2) HIPCHK(c, hipMalloc((void**)&sh, n * sizeof(u64)));
+            HIPCHK(c, hipMemcpyAsync(sl, c->spill_lo, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync(sc, c->spill_cnt, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            if (sh) HIPCHK(c, hipMemcpyAsync(sh, c->spill_hi, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SPILL], 0, sizeof(u64), c->stream));
+            int grid = grid_for(c, n, 256);
+            if (c->KW == 1) hipLaunchKernelGGL(kmc_merge_pairs_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (const u64*)sh, (const u64*)sl, (const u64*)sc, n);
+            else hipLaunchKernelGGL(kmc_merge_pairs_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (const u64*)sh, (const u64*)sl, (const u64*)sc, n);
+            HIPCHK(c, hipGetLastError());
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(sl); (void)hipFree(sc); if (sh) (void)hipFree(sh);
+        }
+        int rc = poll(c);
+        if (rc) return rc;
+    }
+    return fail(c, KMC_ERR_CAPACITY, "table growth did not converge");
+}
+
+int poll_and_settle(kmc_ctx* c) {
+    int rc = poll(c);
+    if (rc) return rc;
+    return settle(c);
+}
+
+// ---- launching the counting kernels ---------------------------------------------------------
+
+int launch_stream(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases,
+                  u64 chunk_begin, u64 chunk_end) {
+    // the kernel indexes chunks from 0; a sub-range is expressed by offsetting the chunk ids
+    u64 n_chunks = chunk_end - chunk_begin;
+    if (!n_chunks) return KMC_OK;
+    u64 max_waves = (u64)c->n_cu * 3 * KMC_STREAM_WAVES;   // 3 workgroups per CU fit (LDS)
+    u64 cpw = (n_chunks + max_waves - 1) / max_waves;
+    if (cpw < 4) cpw = std::min<u64>(4, n_chunks);
+    u64 waves = (n_chunks + cpw - 1) / cpw;
+    int grid = (int)((waves + KMC_STREAM_WAVES - 1) / KMC_STREAM_WAVES);
+    GTable g = gtable_of(c, c->tab);
+    const bool canon = c->cfg.canonical != 0;
+#define LAUNCH_STREAM(KWV, CAN)                                                                          \
+    hipLaunchKernelGGL((kmc_stream_kernel<KWV, CAN>), dim3(grid), dim3(KMC_STREAM_THREADS), 0, c->stream, \
+                       d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, cpw, g)
+    if (c->KW == 1) { if (canon) LAUNCH_STREAM(1, true); else LAUNCH_STREAM(1, false); }
+    else { if (canon) LAUNCH_STREAM(2, true); else LAUNCH_STREAM(2, false); }
+#undef LAUNCH_STREAM
+    HIPCHK(c, hipGetLastError());
+    return KMC_OK;
+}
+
+int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len) {
+    if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
+    c->sorted_valid = false;
+    c->st.n_reads += n_reads;
+    c->st.n_bases += n_bases;
+    c->st.n_batches += 1;
+    if (!n_reads || !n_bases) return KMC_OK;
+
+    int algo = c->cfg.algo;
+    if (c->cfg.mode == KMC_MODE_LR) algo = KMC_ALGO_STREAM;  // LR runs its own kernel inside walk.cuh
+    if (algo == KMC_ALGO_AUTO || algo == KMC_ALGO_WALK) {
+        if (!max_read_len) {
+            HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_MAXLEN], 0, sizeof(u64), c->stream));
+            hipLaunchKernelGGL(kmc_maxlen_kernel, dim3(grid_for(c, n_reads, 256)), dim3(256), 0, c->stream, d_offsets, n_reads, c->d_counters);
+            HIPCHK(c, hipGetLastError());
+            int rc = poll(c);
+            if (rc) return rc;
+            max_read_len = c->h_counters[KMC_CTR_MAXLEN];
+        }
+        bool walk_ok = kmc_walk_supported(c->cfg.k, c->cfg.mode, max_read_len);
+        if (algo == KMC_ALGO_WALK && !walk_ok)
+            return fail(c, KMC_ERR_ARG, "KMC_ALGO_WALK needs k <= %d and reads of at most %d bases (longest here: %llu)",
+                        KMC_WALK_MAX_K, KMC_WALK_MAX_READ, (unsigned long long)max_read_len);
+        algo = walk_ok ? KMC_ALGO_WALK : KMC_ALGO_STREAM;
+    }
+    c->st.algo_last = algo;
+
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    int rc = KMC_OK;
+    if (c->cfg.mode == KMC_MODE_LR) {
+        rc = kmc_lr_launch(c->stream, c->n_cu, d_bases, d_offsets, n_reads, n_bases, gtable_of(c, c->tab));
+        if (rc) return fail(c, rc, "LR kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        c->pending = true;
+    } else if (algo == KMC_ALGO_WALK) {
+        size_t ws_bytes = kmc_walk_workspace_bytes(c->n_cu, c->KW);
+        rc = ensure(c, c->walk_ws, ws_bytes);
+        if (rc) return rc;
+        rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_offsets, n_reads, n_bases,
+                             max_read_len, c->walk_ws.p, gtable_of(c, c->tab));
+        if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        c->pending = true;
+    } else {
+        // Sub-batches by chunk range.  A sub-batch of n k-mers can add at most n new keys, so the
+        // first one is sized to what the table and spill area can absorb for certain; later ones
+        // ramp up using the observed ratio of new keys per k-mer (x16 per step at most).
+        const u64 n_chunks = (n_bases + KMC_CHUNK - 1) / KMC_CHUNK;
+        u64 done = 0, prev = 0;
+        while (done < n_chunks) {
+            u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
+            u64 freeslots = (c->tab.cap * 7 / 10 > occ ? c->tab.cap * 7 / 10 - occ : 0) + c->spill_cap / 2;
+            u64 safe = std::max<u64>(freeslots / KMC_CHUNK, 1);
+            u64 take = safe;
+            if (prev) {
+                double rho = std::max(c->rho_max, 1e-9);
+                double opt = (double)freeslots / (4.0 * rho) / KMC_CHUNK;
+                u64 ramp = prev * 16;
+                take = std::max<u64>(safe, (u64)std::min<double>(opt, (double)ramp));
+            }
+            take = std::min<u64>(take, n_chunks - done);
+            rc = launch_stream(c, d_bases, d_offsets, n_reads, n_bases, done, done + take);
+            if (rc) return rc;
+            c->pending = true;
+            done += take;
+            prev = take;
+            if (done < n_chunks) {
+                u64 occ_before = occ;
+                rc = poll_and_settle(c);
+                if (rc) return rc;
+                u64 occ_after = c->h_counters[KMC_CTR_OCCUPIED];
+                double rho = (double)(occ_after > occ_before ? occ_after - occ_before : 0) / ((double)take * KMC_CHUNK);
+                c->rho_max = std::max(c->rho_max, rho);
+            }
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    return KMC_OK;
+}
+
+template <typename K>
+int sort_pairs(kmc_ctx* c, const K* kin, K* kout, const u64* vin, u64* vout, u64 n, unsigned bits) {
+    size_t tmp = 0;
+    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, (size_t)n, 0u, bits, c->stream));
+    int rc = ensure(c, c->sort_tmp, tmp);
+    if (rc) return rc;
+    HIPCHK(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, kin, kout, vin, vout, (size_t)n, 0u, bits, c->stream));
+    return KMC_OK;
+}
+
+}  // namespace
+
+// ---- ABI -------------------------------------------------------------------------------------
+
+extern "C" const char* kmc_version(void) { return "libkmc 0.1 (gfx950)"; }
+
+extern "C" const char* kmc_status_string(int s) {
+    switch (s) {
+        case KMC_OK: return "ok";
+        case KMC_ERR_ARG: return "bad argument";
+        case KMC_ERR_NO_DEVICE: return "no usable HIP device (libkmc has no CPU fallback)";
+        case KMC_ERR_HIP: return "HIP runtime error";
+        case KMC_ERR_NOMEM: return "out of memory";
+        case KMC_ERR_IO: return "Error during opening the file";
+        case KMC_ERR_FORMAT: return "Expected > at record start.";
+        case KMC_ERR_ALPHABET: return "Unexpected charactor in sequence";
+        case KMC_ERR_CAPACITY: return "count table capacity exhausted";
+        case KMC_ERR_STATE: return "call out of order";
+        default: return "unknown status";
+    }
+}
+
+extern "C" const char* kmc_last_error(const kmc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+extern "C" void kmc_destroy(kmc_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    free_table(c->tab);
+    if (c->d_counters) (void)hipFree(c->d_counters);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->spill_hi) (void)hipFree(c->spill_hi);
+    if (c->spill_lo) (void)hipFree(c->spill_lo);
+    if (c->spill_cnt) (void)hipFree(c->spill_cnt);
+    DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
+                      &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws};
+    for (DevBuf* b : bufs) free_buf(*b);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int kmc_create(kmc_ctx** out, const kmc_config* cfg) {
+    if (!out || !cfg) return fail(nullptr, KMC_ERR_ARG, "null argument");
+    *out = nullptr;
+    if (cfg->struct_size != sizeof(kmc_config)) return fail(nullptr, KMC_ERR_ARG, "kmc_config.struct_size mismatch (%u != %zu)", cfg->struct_size, sizeof(kmc_config));
+    if (cfg->mode != KMC_MODE_CONTIG && cfg->mode != KMC_MODE_LR) return fail(nullptr, KMC_ERR_ARG, "bad mode %d", cfg->mode);
+    if (cfg->mode == KMC_MODE_CONTIG && (cfg->k < 1 || cfg->k > 63)) return fail(nullptr, KMC_ERR_ARG, "k must be in 1..63 (got %d)", cfg->k);
+    if (cfg->algo < KMC_ALGO_AUTO || cfg->algo > KMC_ALGO_WALK) return fail(nullptr, KMC_ERR_ARG, "bad algo %d", cfg->algo);
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) return fail(nullptr, KMC_ERR_NO_DEVICE, "no usable HIP device (%s); libkmc has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, KMC_ERR_ARG, "device %d out of range (0..%d)", cfg->device, ndev - 1);
+    kmc_ctx* c = new (std::nothrow) kmc_ctx();
+    if (!c) return fail(nullptr, KMC_ERR_NOMEM, "out of memory");
+    c->cfg = *cfg;
+    if (cfg->mode == KMC_MODE_LR) { c->KW = 2; c->klen = 54; c->cfg.k = 54; c->cfg.canonical = 0; }
+    else { c->KW = cfg->k <= 31 ? 1 : 2; c->klen = cfg->k; }
+    int rc = KMC_OK;
+    auto body = [&]() -> int {
+        HIPCHK(c, hipSetDevice(cfg->device));
+        hipDeviceProp_t prop;
+        HIPCHK(c, hipGetDeviceProperties(&prop, cfg->device));
+        c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
+        else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
+        HIPCHK(c, hipEventCreate(&c->ev0));
+        HIPCHK(c, hipEventCreate(&c->ev1));
+        HIPCHK(c, hipMalloc((void**)&c->d_counters, KMC_CTR_N * sizeof(u64)));
+        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, KMC_CTR_N * sizeof(u64), c->stream));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_counters, KMC_CTR_N * sizeof(u64)));
+        memset(c->h_counters, 0, KMC_CTR_N * sizeof(u64));
+        u64 cap = next_pow2(std::max<u64>(cfg->capacity_hint * 2, 1ull << 22));
+        c->spill_cap = std::max<u64>(cap / 4, 1ull << 20);
+        HIPCHK(c, hipMalloc((void**)&c->spill_lo, c->spill_cap * sizeof(u64)));
+        HIPCHK(c, hipMalloc((void**)&c->spill_cnt, c->spill_cap * sizeof(u64)));
+        if (c->KW == 2) HIPCHK(c, hipMalloc((void**)&c->spill_hi, c->spill_cap * sizeof(u64)));
+        int r = alloc_table(c, c->tab, cap);
+        if (r) return r;
+        c->st.table_capacity = cap;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return KMC_OK;
+    };
+    rc = body();
+    if (rc) {
+        g_create_err = c->err;
+        kmc_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return KMC_OK;
+}
+
+extern "C" int kmc_reset(kmc_ctx* c) {
+    if (!c) return KMC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->KW == 2) {
+        HIPCHK(c, hipMemsetAsync(c->tab.hi, 0xFF, c->tab.cap * sizeof(u64), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->tab.lo, 0, c->tab.cap * sizeof(u64), c->stream));
+    } else {
+        HIPCHK(c, hipMemsetAsync(c->tab.lo, 0xFF, c->tab.cap * sizeof(u64), c->stream));
+    }
+    HIPCHK(c, hipMemsetAsync(c->tab.cnt, 0, c->tab.cap * sizeof(u64), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, KMC_CTR_N * sizeof(u64), c->stream));
+    memset(c->h_counters, 0, KMC_CTR_N * sizeof(u64));
+    c->pending = false;
+    c->sorted_valid = false;
+    c->n_sorted = 0;
+    u64 cap = c->st.table_capacity;
+    c->st = kmc_stats{};
+    c->st.table_capacity = cap;
+    return KMC_OK;
+}
+
+extern "C" int kmc_add_batch_device(kmc_ctx* c, const void* d_bases, const void* d_offsets, uint64_t n_reads,
+                                    uint64_t n_bases, uint64_t max_read_len) {
+    if (!c) return KMC_ERR_ARG;
+    if (n_reads && (!d_bases || !d_offsets)) return fail(c, KMC_ERR_ARG, "null device pointer");
+    if (((uintptr_t)d_bases & 15) != 0) return fail(c, KMC_ERR_ARG, "d_bases must be 16-byte aligned");
+    if (((uintptr_t)d_offsets & 7) != 0) return fail(c, KMC_ERR_ARG, "d_offsets must be 8-byte aligned");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    return count_batch_device(c, (const uint8_t*)d_bases, (const u64*)d_offsets, n_reads, n_bases, max_read_len);
+}
+
+extern "C" int kmc_add_batch(kmc_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads) {
+    if (!c) return KMC_ERR_ARG;
+    if (!n_reads) { c->st.n_batches += 1; return KMC_OK; }
+    if (!bases || !offsets) return fail(c, KMC_ERR_ARG, "null buffer");
+    if (offsets[0] != 0) return fail(c, KMC_ERR_ARG, "offsets[0] must be 0");
+    u64 maxlen = 0;
+    for (u64 i = 0; i < n_reads; ++i) {
+        if (offsets[i + 1] < offsets[i]) return fail(c, KMC_ERR_ARG, "offsets must be non-decreasing (read %llu)", (unsigned long long)i);
+        maxlen = std::max<u64>(maxlen, offsets[i + 1] - offsets[i]);
+    }
+    const u64 n_bases = offsets[n_reads];
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }  // previous batch may still read the staging area
+    int rc = ensure(c, c->st_bases, n_bases + 64);
+    if (rc) return rc;
+    rc = ensure(c, c->st_offsets, (n_reads + 1) * sizeof(u64));
+    if (rc) return rc;
+    if (n_bases) HIPCHK(c, hipMemcpyAsync(c->st_bases.p, bases, n_bases, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->st_offsets.p, offsets, (n_reads + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // caller may reuse its buffers on return
+    return count_batch_device(c, (const uint8_t*)c->st_bases.p, (const u64*)c->st_offsets.p, n_reads, n_bases, maxlen);
+}
+
+extern "C" int kmc_merge_pairs_device(kmc_ctx* c, const void* d_key_hi, const void* d_key_lo, const void* d_count, uint64_t n) {
+    if (!c) return KMC_ERR_ARG;
+    if (!n) return KMC_OK;
+    if (!d_key_lo || !d_count) return fail(c, KMC_ERR_ARG, "null device pointer");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
+    // make room for the worst case (every pair new)
+    u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
+    if ((occ + n) * 2 > c->tab.cap) {
+        int rc = grow_to(c, next_pow2((occ + n) * 2));
+        if (rc) return rc;
+    }
+    c->sorted_valid = false;
+    GTable g = gtable_of(c, c->tab);
+    int grid = grid_for(c, n, 256);
+    if (c->KW == 1) hipLaunchKernelGGL(kmc_merge_pairs_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (const u64*)nullptr, (const u64*)d_key_lo, (const u64*)d_count, n);
+    else hipLaunchKernelGGL(kmc_merge_pairs_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (const u64*)d_key_hi, (const u64*)d_key_lo, (const u64*)d_count, n);
+    HIPCHK(c, hipGetLastError());
+    c->pending = true;
+    return KMC_OK;
+}
+
+extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total) {
+    if (!c) return KMC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = poll_and_settle(c);
+    if (rc) return rc;
+    const u64 n = c->h_counters[KMC_CTR_OCCUPIED];
+    const size_t nb = (size_t)std::max<u64>(n, 1) * sizeof(u64);
+    DevBuf* need[] = {&c->o_lo, &c->o_cnt, &c->t_lo, &c->t_cnt, &c->t_idx0, &c->t_idx1, &c->t_key};
+    for (DevBuf* b : need) { rc = ensure(c, *b, nb); if (rc) return rc; }
+    if (c->KW == 2) { rc = ensure(c, c->o_hi, nb); if (rc) return rc; rc = ensure(c, c->t_hi, nb); if (rc) return rc; }
+    if (n) {
+        HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_OUT], 0, sizeof(u64), c->stream));
+        GTable g = gtable_of(c, c->tab);
+        int grid = grid_for(c, c->tab.cap, 256);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_compact_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->t_lo.p, (u64*)c->t_cnt.p);
+        else hipLaunchKernelGGL(kmc_compact_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)c->t_hi.p, (u64*)c->t_lo.p, (u64*)c->t_cnt.p);
+        HIPCHK(c, hipGetLastError());
+        int g2 = grid_for(c, n, 256);
+        hipLaunchKernelGGL(kmc_iota_kernel, dim3(g2), dim3(256), 0, c->stream, (u64*)c->t_idx0.p, n);
+        const unsigned kb = 2u * (unsigned)c->klen;
+        if (c->KW == 1) {
+            rc = sort_pairs<u64>(c, (const u64*)c->t_lo.p, (u64*)c->o_lo.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, std::max(kb, 1u));
+            if (rc) return rc;
+            hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_cnt.p, (const u64*)c->t_idx1.p, (u64*)c->o_cnt.p, n);
+        } else {
+            // LSD over two words: stable sort by lo, then by hi
+            rc = sort_pairs<u64>(c, (const u64*)c->t_lo.p, (u64*)c->t_key.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, 64u);
+            if (rc) return rc;
+            hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_hi.p, (const u64*)c->t_idx1.p, (u64*)c->t_key.p, n);
+            rc = sort_pairs<u64>(c, (const u64*)c->t_key.p, (u64*)c->o_hi.p, (const u64*)c->t_idx1.p, (u64*)c->t_idx0.p, n, kb > 64 ? kb - 64 : 1u);
+            if (rc) return rc;
+            hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_lo.p, (const u64*)c->t_idx0.p, (u64*)c->o_lo.p, n);
+            hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_cnt.p, (const u64*)c->t_idx0.p, (u64*)c->o_cnt.p, n);
+        }
+        HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM], 0, sizeof(u64), c->stream));
+        hipLaunchKernelGGL(kmc_sum_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->o_cnt.p, n, c->d_counters);
+        HIPCHK(c, hipGetLastError());
+        rc = poll(c);
+        if (rc) return rc;
+    }
+    c->n_sorted = n;
+    c->sorted_valid = true;
+    c->st.n_distinct = n;
+    c->st.n_kmers = n ? c->h_counters[KMC_CTR_SUM] : 0;
+    float ms = 0.f;
+    if (c->st.n_batches && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->st.kernel_ms_last = ms;
+    if (n_distinct) *n_distinct = n;
+    if (n_total) *n_total = c->st.n_kmers;
+    return KMC_OK;
+}
+
+extern "C" int kmc_export(kmc_ctx* c, uint64_t* key_hi, uint64_t* key_lo, uint64_t* count, uint64_t cap) {
+    if (!c) return KMC_ERR_ARG;
+    if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_export before kmc_finalize");
+    const u64 n = c->n_sorted;
+    if (cap < n) return fail(c, KMC_ERR_ARG, "export capacity %llu < %llu distinct keys", (unsigned long long)cap, (unsigned long long)n);
+    if (!n) return KMC_OK;
+    if (!key_lo || !count) return fail(c, KMC_ERR_ARG, "null buffer");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipMemcpyAsync(key_lo, c->o_lo.p, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(count, c->o_cnt.p, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    if (key_hi) {
+        if (c->KW == 2) HIPCHK(c, hipMemcpyAsync(key_hi, c->o_hi.p, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        else memset(key_hi, 0, n * sizeof(u64));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
+extern "C" int kmc_export_device(kmc_ctx* c, const void** d_key_hi, const void** d_key_lo, const void** d_count, uint64_t* n_distinct) {
+    if (!c) return KMC_ERR_ARG;
+    if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_export_device before kmc_finalize");
+    if (d_key_hi) *d_key_hi = c->KW == 2 ? c->o_hi.p : nullptr;
+    if (d_key_lo) *d_key_lo = c->o_lo.p;
+    if (d_count) *d_count = c->o_cnt.p;
+    if (n_distinct) *n_distinct = c->n_sorted;
+    return KMC_OK;
+}
+
+extern "C" uint32_t kmc_owner_of(uint64_t key_hi, uint64_t key_lo, uint32_t n_parts) { return kmc_owner(key_hi, key_lo, n_parts); }
+
+extern "C" int kmc_partition_device(kmc_ctx* c, uint32_t n_parts, uint64_t* part_begin, const void** d_key_hi,
+                                    const void** d_key_lo, const void** d_count) {
+    if (!c || !n_parts || !part_begin) return KMC_ERR_ARG;
+    if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_partition_device before kmc_finalize");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const u64 n = c->n_sorted;
+    const size_t nb = (size_t)std::max<u64>(n, 1) * sizeof(u64);
+    int rc;
+    DevBuf* need[] = {&c->p_lo, &c->p_cnt, &c->t_idx0, &c->t_idx1, &c->t_key, &c->t_lo};
+    for (DevBuf* b : need) { rc = ensure(c, *b, nb); if (rc) return rc; }
+    if (c->KW == 2) { rc = ensure(c, c->p_hi, nb); if (rc) return rc; }
+    std::vector<u64> owners((size_t)n);
+    if (n) {
+        int g2 = grid_for(c, n, 256);
+        hipLaunchKernelGGL(kmc_owner_kernel, dim3(g2), dim3(256), 0, c->stream, c->KW == 2 ? (const u64*)c->o_hi.p : (const u64*)nullptr,
+                           (const u64*)c->o_lo.p, n, n_parts, (u64*)c->t_key.p);
+        hipLaunchKernelGGL(kmc_iota_kernel, dim3(g2), dim3(256), 0, c->stream, (u64*)c->t_idx0.p, n);
+        unsigned bits = 1;
+        while ((1ull << bits) < n_parts) bits++;
+        rc = sort_pairs<u64>(c, (const u64*)c->t_key.p, (u64*)c->t_lo.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, bits);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->o_lo.p, (const u64*)c->t_idx1.p, (u64*)c->p_lo.p, n);
+        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->o_cnt.p, (const u64*)c->t_idx1.p, (u64*)c->p_cnt.p, n);
+        if (c->KW == 2) hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->o_hi.p, (const u64*)c->t_idx1.p, (u64*)c->p_hi.p, n);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(owners.data(), c->t_lo.p, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    u64 pos = 0;
+    for (u32 p = 0; p <= n_parts; ++p) {
+        while (pos < n && owners[(size_t)pos] < p) pos++;
+        part_begin[p] = pos;
+    }
+    part_begin[n_parts] = n;
+    if (d_key_hi) *d_key_hi = c->KW == 2 ? c->p_hi.p : nullptr;
+    if (d_key_lo) *d_key_lo = c->p_lo.p;
+    if (d_count) *d_count = c->p_cnt.p;
+    return KMC_OK;
+}
+
+extern "C" int kmc_get_stats(const kmc_ctx* c, kmc_stats* out) {
+    if (!c || !out) return KMC_ERR_ARG;
+    *out = c->st;
+    return KMC_OK;
+}
+
+extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
+    if (!c || !path) return KMC_ERR_ARG;
+    kmc_reads rd;
+    char eb[256] = {0};
+    int rc = kmc_parse_fasta(path, &rd, eb, sizeof(eb));
+    if (rc) return fail(c, rc, "%s: %s", path, eb);
+    if (c->cfg.mode == KMC_MODE_LR) {
+        // the reference aborts on any non-ACGT character (main.rs:23)
+        for (u64 i = 0; i < rd.n_bases; ++i) {
+            uint8_t b = rd.bases[i];
+            if (b != 'A' && b != 'C' && b != 'G' && b != 'T') {
+                kmc_free_reads(&rd);
+                return fail(c, KMC_ERR_ALPHABET, "Unexpected charactor %c appears", b);
+            }
+        }
+    }
+    // batches of at most ~1 GiB of bases, cut at read boundaries
+    const u64 BATCH = 1ull << 30;
+    u64 r0 = 0;
+    std::vector<u64> offs;
+    while (r0 < rd.n_reads && !rc) {
+        u64 r1 = r0 + 1;
+        while (r1 < rd.n_reads && rd.offsets[r1 + 1] - rd.offsets[r0] <= BATCH) r1++;
+        offs.resize((size_t)(r1 - r0 + 1));
+        for (u64 i = r0; i <= r1; ++i) offs[(size_t)(i - r0)] = rd.offsets[i] - rd.offsets[r0];
+        rc = kmc_add_batch(c, rd.bases + rd.offsets[r0], offs.data(), r1 - r0);
+        r0 = r1;
+    }
+    kmc_free_reads(&rd);
+    if (rc) return rc;
+    return kmc_finalize(c, n_distinct, n_total);
+}
+
+extern "C" int kmc_synth_reads_device(const kmc_synth* s, uint64_t first_record, uint64_t n_records, void* d_bases,
+                                      void* d_offsets, int device, void* stream) {
+    if (!s || !d_bases || !d_offsets || !s->line_len || !s->lines_per_record) return KMC_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return KMC_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    const u64 read_len = (u64)s->lines_per_record * s->line_len;
+    const u64 n_bases = n_records * read_len;
+    uint8_t* d_pool = nullptr;
+    if (s->pool) {
+        std::vector<uint8_t> pool((size_t)s->pool * s->line_len);
+        for (u32 p = 0; p < s->pool; ++p)
+            for (u32 x = 0; x < s->line_len; ++x) pool[(size_t)p * s->line_len + x] = kmc_synth_pool_base(s->seed, s->line_len, p, x);
+        if (hipMalloc((void**)&d_pool, pool.size()) != hipSuccess) return KMC_ERR_NOMEM;
+        if (hipMemcpy(d_pool, pool.data(), pool.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(d_pool); return KMC_ERR_HIP; }
+    }
+    u64 n16 = (n_bases + 15) / 16;
+    int grid = (int)std::min<u64>((n16 + 255) / 256, 256 * 16);
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(kmc_synth_kernel, dim3(grid), dim3(256), 0, st, s->seed, s->pool, s->line_len, s->lines_per_record,
+                       first_record, n_bases, (const uint8_t*)d_pool, (uint8_t*)d_bases);
+    int g2 = (int)std::min<u64>((n_records + 256) / 256, 256 * 16);
+    hipLaunchKernelGGL(kmc_synth_offsets_kernel, dim3(g2), dim3(256), 0, st, n_records, read_len, (u64*)d_offsets);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (d_pool) (void)hipFree(d_pool);
+    return e == hipSuccess ? KMC_OK : KMC_ERR_HIP;
+}

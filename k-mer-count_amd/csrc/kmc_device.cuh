@@ -1,0 +1,204 @@
+// kmc_device.cuh -- device-side building blocks shared by the gfx950 kernels.
+//
+// Written for CDNA4 (wave64, LDS atomics, v_alignbit/v_perm/v_bfrev) only; there is no other
+// backend.  Semantics follow SURVEY.md 8a-def: alphabet A=0 C=1 G=2 T=3 (reference
+// k-mer-count/src/main.rs:19-22), MSB-first packing so that unsigned key order equals the
+// reference's string order (main.rs:87), canonical = min(fwd, revcomp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define KMC_EMPTY64 (~0ull)
+#define KMC_LOCKED64 (~0ull - 1ull)
+
+// counters[] layout (device, u64 each)
+enum { KMC_CTR_OCCUPIED = 0, KMC_CTR_SPILL = 1, KMC_CTR_ERR = 2, KMC_CTR_KMERS = 3, KMC_CTR_MAXLEN = 4,
+       KMC_CTR_OUT = 5, KMC_CTR_BADBASE = 6, KMC_CTR_SUM = 7, KMC_CTR_N = 8 };
+
+// Global (HBM) open-addressing count table.  One-word keys (KW==1, k<=31) use key_lo only and
+// KMC_EMPTY64 as the empty marker (a 62-bit key can never equal it).  Two-word keys (KW==2,
+// 32<=k<=63 and the 108-bit LR keys) claim a slot by CAS on key_hi EMPTY->LOCKED, publish
+// key_lo, then release key_hi; key_hi < 2^62 so neither marker is a real key.
+struct GTable {
+    u64* key_hi;
+    u64* key_lo;
+    u64* count;
+    u64  capmask;  // capacity - 1 (capacity is a power of two)
+    u64* counters; // KMC_CTR_*
+    u64* spill_hi;
+    u64* spill_lo;
+    u64* spill_cnt;
+    u64  spill_cap;
+};
+
+__device__ __forceinline__ u64 kmc_mix64(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+template <int KW>
+__device__ __forceinline__ u64 kmc_hash_key(u64 hi, u64 lo) {
+    if (KW == 2) lo ^= kmc_mix64(hi + 0x9E3779B97F4A7C15ull);
+    return kmc_mix64(lo);
+}
+
+// Cheap 32-bit slot hash for the LDS tables (two v_mul_lo_u32 + a few xors).
+template <int KW>
+__device__ __forceinline__ u32 kmc_hash32(u64 hi, u64 lo) {
+    u32 a = (u32)lo, b = (u32)(lo >> 32);
+    u32 h = a * 0x9E3779B1u ^ b * 0x85EBCA77u;
+    if (KW == 2) {
+        u32 c = (u32)hi, d = (u32)(hi >> 32);
+        h ^= c * 0xC2B2AE3Du ^ d * 0x27D4EB2Fu;
+    }
+    h ^= h >> 15;
+    return h;
+}
+
+__device__ __forceinline__ u64 ld_relaxed(const u64* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ void kmc_spill(const GTable& g, u64 hi, u64 lo, u64 cnt) {
+    u64 idx = atomicAdd((unsigned long long*)&g.counters[KMC_CTR_SPILL], 1ull);
+    if (idx < g.spill_cap) {
+        if (g.spill_hi) g.spill_hi[idx] = hi;
+        g.spill_lo[idx] = lo;
+        g.spill_cnt[idx] = cnt;
+    } else {
+        atomicOr((unsigned long long*)&g.counters[KMC_CTR_ERR], 1ull);
+    }
+}
+
+// Add `cnt` occurrences of key (hi,lo) to the global table.  Lock-free; any number of
+// workgroups on any XCD may call it concurrently (device-scope atomics only).
+// Every iteration of the retry loop is a flat if/else chain with no inner spin, so a lane that
+// finds a slot LOCKED by another lane of its own wave simply comes round again after that lane
+// has published -- no intra-wave deadlock.
+template <int KW>
+__device__ __forceinline__ void gtable_add(const GTable& g, u64 hi, u64 lo, u64 cnt) {
+    u64 h = kmc_hash_key<KW>(hi, lo) & g.capmask;
+    u64 probes = 0;
+    const u64 max_probes = g.capmask < 4095 ? g.capmask + 1 : 4096;
+    bool done = false;
+    while (!done) {
+        if (KW == 1) {
+            u64 cur = ld_relaxed(&g.key_lo[h]);
+            if (cur == KMC_EMPTY64) {
+                cur = atomicCAS((unsigned long long*)&g.key_lo[h], KMC_EMPTY64, lo);
+                if (cur == KMC_EMPTY64) {
+                    atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
+                    cur = lo;
+                }
+            }
+            if (cur == lo) {
+                atomicAdd((unsigned long long*)&g.count[h], cnt);
+                done = true;
+            } else {
+                h = (h + 1) & g.capmask;
+                if (++probes >= max_probes) { kmc_spill(g, hi, lo, cnt); done = true; }
+            }
+        } else {
+            u64 cur = __hip_atomic_load(&g.key_hi[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+            if (cur == KMC_EMPTY64) {
+                u64 old = atomicCAS((unsigned long long*)&g.key_hi[h], KMC_EMPTY64, KMC_LOCKED64);
+                if (old == KMC_EMPTY64) {
+                    __hip_atomic_store(&g.key_lo[h], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&g.key_hi[h], hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
+                    atomicAdd((unsigned long long*)&g.count[h], cnt);
+                    done = true;
+                }
+                // else: somebody else owns it now; look again next iteration
+            } else if (cur == KMC_LOCKED64) {
+                // being published; look again next iteration
+            } else if (cur == hi && ld_relaxed(&g.key_lo[h]) == lo) {
+                atomicAdd((unsigned long long*)&g.count[h], cnt);
+                done = true;
+            } else {
+                h = (h + 1) & g.capmask;
+                if (++probes >= max_probes) { kmc_spill(g, hi, lo, cnt); done = true; }
+            }
+        }
+    }
+}
+
+// ---- bit helpers ---------------------------------------------------------------------------
+
+// (hi:lo) >> s, low 32 bits; s in [0,31]  -> v_alignbit_b32
+__device__ __forceinline__ u32 alignbit(u32 hi, u32 lo, u32 s) { return __builtin_amdgcn_alignbit(hi, lo, s); }
+
+// swap the two bits of every 2-bit pair
+__device__ __forceinline__ u32 pairswap(u32 x) { return ((x & 0x55555555u) << 1) | ((x >> 1) & 0x55555555u); }
+
+// 16 bases little-endian (base j at bits 2j..2j+1)  <->  big-endian (base j at bits 31-2j..30-2j)
+__device__ __forceinline__ u32 le_to_be(u32 wle) { return pairswap(__builtin_bitreverse32(wle)); }
+
+// Reverse-complement word of a big-endian 16-base word, itself big-endian:
+// complement every base and reverse their order == ~(little-endian form).
+__device__ __forceinline__ u32 rc_word_be(u32 wbe) { return ~le_to_be(wbe); }
+
+// 4 ASCII bytes -> 2-bit codes in place (one code in the low 2 bits of each byte).
+// 'A'=0x41 'C'=0x43 'G'=0x47 'T'=0x54: (c>>1)&3 = 0,1,3,2; x ^= x>>1 fixes G/T to 2,3.
+__device__ __forceinline__ u32 ascii4_to_codes(u32 v) {
+    u32 t = (v >> 1) & 0x03030303u;
+    return t ^ ((t >> 1) & 0x01010101u);
+}
+// the ASCII the codes stand for; differs from the input exactly at non-ACGT bytes (v_perm_b32 as
+// a 4-entry byte LUT)
+__device__ __forceinline__ u32 codes_to_ascii4(u32 t) { return __builtin_amdgcn_perm(0u, 0x54474341u, t); }
+// 4 codes -> 8 bits, first byte in the low pair
+__device__ __forceinline__ u32 pack4_le(u32 t) {
+    u32 x = t | (t >> 6);
+    return (x | (x >> 12)) & 0xFFu;
+}
+// one bit per non-zero byte of x (bit i <=> byte i)
+__device__ __forceinline__ u32 nonzero_bytes4(u32 x) {
+    u32 nz = ((x | ((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu)) >> 7) & 0x01010101u;
+    return (nz | (nz >> 7) | (nz >> 14) | (nz >> 21)) & 0xFu;
+}
+
+// Encode 16 ASCII bases (as loaded: v.x holds bytes 0..3).  wle: little-endian 2-bit word.
+// anyx != 0 iff some byte is not one of ACGT; exact per-base flags via bad16_from().
+struct Enc16 { u32 wle; u32 x0, x1, x2, x3; };
+__device__ __forceinline__ Enc16 encode16(uint4 v) {
+    Enc16 e;
+    u32 t0 = ascii4_to_codes(v.x), t1 = ascii4_to_codes(v.y), t2 = ascii4_to_codes(v.z), t3 = ascii4_to_codes(v.w);
+    e.x0 = v.x ^ codes_to_ascii4(t0);
+    e.x1 = v.y ^ codes_to_ascii4(t1);
+    e.x2 = v.z ^ codes_to_ascii4(t2);
+    e.x3 = v.w ^ codes_to_ascii4(t3);
+    e.wle = pack4_le(t0) | (pack4_le(t1) << 8) | (pack4_le(t2) << 16) | (pack4_le(t3) << 24);
+    return e;
+}
+__device__ __forceinline__ u32 bad16_from(const Enc16& e) {
+    return nonzero_bytes4(e.x0) | (nonzero_bytes4(e.x1) << 4) | (nonzero_bytes4(e.x2) << 8) | (nonzero_bytes4(e.x3) << 12);
+}
+
+// reverse complement of a 2k-bit key held in (hi,lo) (used off the hot loop: flush, LR mode)
+__device__ __forceinline__ void revcomp_key(u64 hi, u64 lo, int k, u64& rhi, u64& rlo) {
+    // complement + reverse 128 bits pairwise, then shift right by 128-2k
+    u64 a = ~lo, b = ~hi;
+    u64 ra = __builtin_bitreverse64(a), rb = __builtin_bitreverse64(b);
+    ra = ((ra & 0x5555555555555555ull) << 1) | ((ra >> 1) & 0x5555555555555555ull);
+    rb = ((rb & 0x5555555555555555ull) << 1) | ((rb >> 1) & 0x5555555555555555ull);
+    // 128-bit value (ra:rb) = revcomp of the full 64 bases; keep the top 2k bits
+    int sh = 128 - 2 * k;
+    if (sh >= 64) { rlo = ra >> (sh - 64); rhi = 0; if (sh == 64) rlo = ra; }
+    else if (sh == 0) { rhi = ra; rlo = rb; }
+    else { rlo = (rb >> sh) | (ra << (64 - sh)); rhi = ra >> sh; }
+}
+
+__device__ __forceinline__ bool key_less(u64 ahi, u64 alo, u64 bhi, u64 blo) {
+    return ahi < bhi || (ahi == bhi && alo < blo);
+}
+
+__device__ __forceinline__ u64 wave_sum_u64(u64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}

@@ -1,0 +1,85 @@
+// kmc_table.cuh -- maintenance kernels of the global count table: the GPU side of the
+// reference's grouping/ordering step (k-mer-count/src/main.rs:84,87): compaction of occupied
+// slots, rehash on growth, merging (key,count) pairs (spill drain, multi-GPU reduce), owner
+// partition for the all-to-all, and small utilities.
+#pragma once
+#include "kmc_device.cuh"
+
+template <int KW>
+__global__ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_cnt) {
+    const u64 cap = g.capmask + 1;
+    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (u64)gridDim.x * blockDim.x) {
+        bool occ = (KW == 1) ? (g.key_lo[s] != KMC_EMPTY64) : (g.key_hi[s] != KMC_EMPTY64);
+        if (occ) {
+            u64 idx = atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OUT], 1ull);
+            if (KW == 2) out_hi[idx] = g.key_hi[s];
+            out_lo[idx] = g.key_lo[s];
+            out_cnt[idx] = g.count[s];
+        }
+    }
+}
+
+// re-insert every entry of `old` into `g` (growth)
+template <int KW>
+__global__ void kmc_rehash_kernel(GTable old, GTable g) {
+    const u64 cap = old.capmask + 1;
+    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (u64)gridDim.x * blockDim.x) {
+        bool occ = (KW == 1) ? (old.key_lo[s] != KMC_EMPTY64) : (old.key_hi[s] != KMC_EMPTY64);
+        if (occ) gtable_add<KW>(g, KW == 2 ? old.key_hi[s] : 0ull, old.key_lo[s], old.count[s]);
+    }
+}
+
+// add n (key,count) pairs to the table
+template <int KW>
+__global__ void kmc_merge_pairs_kernel(GTable g, const u64* hi, const u64* lo, const u64* cnt, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        u64 c = cnt[i];
+        if (c) gtable_add<KW>(g, (KW == 2 && hi) ? hi[i] : 0ull, lo[i], c);
+    }
+}
+
+__global__ void kmc_gather_u64_kernel(const u64* src, const u64* idx, u64* dst, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+
+__global__ void kmc_iota_kernel(u64* dst, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[i] = i;
+}
+
+// longest read of a batch -> counters[KMC_CTR_MAXLEN] (atomicMax), used when the caller of
+// kmc_add_batch_device does not know it
+__global__ void kmc_maxlen_kernel(const u64* offsets, u64 n_reads, u64* counters) {
+    u64 m = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += (u64)gridDim.x * blockDim.x) {
+        u64 l = offsets[i + 1] - offsets[i];
+        m = l > m ? l : m;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        u64 t = __shfl_xor(m, o);
+        m = t > m ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax((unsigned long long*)&counters[KMC_CTR_MAXLEN], m);
+}
+
+// owner of a key for the multi-GPU all-to-all (same function as kmc_owner_of on the host)
+__host__ __device__ inline u32 kmc_owner(u64 hi, u64 lo, u32 n_parts) {
+    u64 z = lo ^ (hi * 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (u32)((z >> 32) * (u64)n_parts >> 32);
+}
+
+__global__ void kmc_owner_kernel(const u64* hi, const u64* lo, u64 n, u32 n_parts, u64* owner_out) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        owner_out[i] = kmc_owner(hi ? hi[i] : 0ull, lo[i], n_parts);
+}
+
+// sum of n counts -> counters[KMC_CTR_SUM]
+__global__ void kmc_sum_kernel(const u64* cnt, u64 n, u64* counters) {
+    u64 a = 0;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) a += cnt[i];
+    a = wave_sum_u64(a);
+    if ((threadIdx.x & 63) == 0 && a) atomicAdd((unsigned long long*)&counters[KMC_CTR_SUM], a);
+}

@@ -1,0 +1,39 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+SAMPLE = os.path.join(GOLDEN, "sample.fasta")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def kmc():
+    """The product package.  Builds libkmc.so in-tree if it is missing (hipcc cross-compiles)."""
+    m = importlib.import_module("k-mer-count_amd")
+    if not os.path.exists(m.LIB_PATH):
+        m.build()
+    m.lib()
+    return m
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_py
+    oracle_py.lib()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def sample_path():
+    return SAMPLE

@@ -1,0 +1,143 @@
+"""CPU-side checks of the product library: the C-ABI library loads and exports every symbol
+include/kmc.h declares, the host logic (FASTA reader, generator, key decoding, owner function)
+behaves, and there is no CPU fallback (kmc_create fails loudly without a GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SAMPLE
+
+
+def _has_gpu():
+    return os.path.exists("/dev/kfd")
+
+
+def test_library_exports_every_declared_symbol(kmc):
+    hdr = open(os.path.join(ROOT, "include", "kmc.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = sorted(set(re.findall(r"\b(kmc_[a-z_0-9]+)\s*\(", hdr)))
+    assert declared == sorted(kmc.ABI_SYMBOLS)
+    out = subprocess.run(["nm", "-D", "--defined-only", kmc.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r" T (kmc_[a-z_0-9]+)", out))
+    assert set(declared) <= exported
+    L = kmc.lib()
+    for s in declared:
+        assert getattr(L, s) is not None
+    assert b"gfx950" in L.kmc_version()
+
+
+def test_no_torch_types_in_signatures():
+    hdr = open(os.path.join(ROOT, "include", "kmc.h")).read()
+    assert "torch" not in hdr and "at::" not in hdr and 'extern "C"' in hdr
+
+
+@pytest.mark.skipif(_has_gpu(), reason="CPU-only check")
+def test_create_fails_loudly_without_gpu(kmc):
+    with pytest.raises(kmc.KmcError) as e:
+        kmc.KmerCounter(k=31)
+    assert e.value.status == kmc.ERR_NO_DEVICE
+    assert "no CPU fallback" in str(e.value)
+
+
+def test_create_argument_checks(kmc):
+    L = kmc.lib()
+    h = C.c_void_p()
+    assert L.kmc_create(C.byref(h), None) == kmc.ERR_ARG
+    cfg = kmc._Config(3, 31, 0, 1, 0, 0, 0, None)  # wrong struct_size
+    assert L.kmc_create(C.byref(h), C.byref(cfg)) == kmc.ERR_ARG
+    cfg = kmc._Config(C.sizeof(kmc._Config), 64, 0, 1, 0, 0, 0, None)  # k out of range
+    assert L.kmc_create(C.byref(h), C.byref(cfg)) == kmc.ERR_ARG
+    assert b"1..63" in L.kmc_last_error(None)
+    assert L.kmc_finalize(None, None, None) == kmc.ERR_ARG
+
+
+def test_host_fasta_reader_matches_oracle(kmc, oracle, tmp_path):
+    b1, o1 = kmc.parse_fasta(SAMPLE)
+    b2, o2 = oracle.parse_fasta(SAMPLE)
+    assert np.array_equal(b1, b2) and np.array_equal(o1, o2)
+    assert o1.shape[0] == 201 and int(o1[-1]) == 80000
+    cases = [b">r1 desc\nACGT  \r\nAC\n\n>r2\n>r3\nGG", b"", b">a\n", b">a\nAC\n>\n>b\nGG\n", b">x y z\nAAAA\nCCCC", b">a\r\nAC\r\n>b\r\nGT\r\n"]
+    for i, data in enumerate(cases):
+        p = tmp_path / f"c{i}.fasta"
+        p.write_bytes(data)
+        b1, o1 = kmc.parse_fasta(str(p))
+        b2, o2 = oracle.parse_fasta(str(p))
+        assert np.array_equal(b1, b2) and np.array_equal(o1, o2), data
+    bad = tmp_path / "bad.fasta"
+    bad.write_bytes(b"ACGT\n>r\nAC\n")
+    with pytest.raises(kmc.KmcError) as e:
+        kmc.parse_fasta(str(bad))
+    assert e.value.status == kmc.ERR_FORMAT and "Expected > at record start." in str(e.value)
+    with pytest.raises(kmc.KmcError) as e:
+        kmc.parse_fasta(str(tmp_path / "nope.fasta"))
+    assert e.value.status == kmc.ERR_IO
+
+
+def test_host_fasta_reader_long_lines(kmc, oracle, tmp_path):
+    rng = np.random.default_rng(5)
+    seq = rng.integers(0, 4, 5_000_000)
+    txt = np.frombuffer(b"ACGT", np.uint8)[seq].tobytes()
+    p = tmp_path / "long.fasta"
+    p.write_bytes(b">chr1\n" + txt[:4_500_000] + b"\n" + txt[4_500_000:] + b"\n>chr2\n" + txt[:100])
+    b1, o1 = kmc.parse_fasta(str(p))
+    b2, o2 = oracle.parse_fasta(str(p))
+    assert np.array_equal(b1, b2) and np.array_equal(o1, o2) and o1.tolist() == [0, 5_000_000, 5_000_100]
+
+
+def test_decode_key_and_owner(kmc):
+    L = kmc.lib()
+    buf = C.create_string_buffer(64)
+    L.kmc_decode_key(0, 0b00011011, 4, buf)
+    assert buf.raw[:4] == b"ACGT"
+    L.kmc_decode_key(0b1101, 1 << 63, 34, buf)  # 68 bits: T, C from key_hi, then G, then zeros
+    assert buf.raw[:34] == b"TCG" + b"A" * 31
+    owners = [kmc.owner_of(0, i * 2654435761, 8) for i in range(4000)]
+    assert set(owners) == set(range(8)) and all(kmc.owner_of(5, 7, 1) == 0 for _ in range(2))
+    counts = np.bincount(owners, minlength=8)
+    assert counts.min() > 400
+
+
+def test_synth_generator_distribution(kmc, tmp_path):
+    s = kmc.Synth(seed=7)
+    bases, offs = kmc.synth_reads_host(s, 0, 300)
+    assert offs.tolist() == [400 * i for i in range(301)]
+    lines = bases.reshape(-1, 80)
+    uniq = np.unique(lines, axis=0)
+    assert uniq.shape[0] == 10  # pool of 10 lines, generator :5-8
+    assert set(np.unique(bases).tolist()) == set(b"ACGT")
+    # any record range is generated independently and identically
+    b2, _ = kmc.synth_reads_host(s, 100, 50)
+    assert np.array_equal(b2, bases[100 * 400:150 * 400])
+    # a different seed gives a different pool
+    b3, _ = kmc.synth_reads_host(kmc.Synth(seed=8), 0, 10)
+    assert not np.array_equal(b3, bases[:4000])
+    # pool=0: every line fresh random
+    b4, _ = kmc.synth_reads_host(kmc.Synth(seed=7, pool=0), 0, 100)
+    assert np.unique(b4.reshape(-1, 80), axis=0).shape[0] == 500
+    # FASTA text: header format of generator :11-12, and it parses back to the same reads
+    out = subprocess.run([os.path.join(ROOT, "bin", "kmc-genfasta"), "--records", "300", "--seed", "7"], capture_output=True, check=True).stdout
+    assert out.startswith(b">dummy_sequence_001 1th record\n") and b">dummy_sequence_300 300th record\n" in out
+    p = tmp_path / "g.fasta"
+    p.write_bytes(out)
+    pb, po = kmc.parse_fasta(str(p))
+    assert np.array_equal(pb, bases) and np.array_equal(po, offs)
+    # size parameter: smallest record count reaching N bytes, exact size reported
+    for nbytes in (1, 436, 437, 87_492, 1_000_000, 12_345_678):
+        n, exact = kmc.synth_records_for_bytes(s, nbytes)
+        assert exact >= nbytes
+        if nbytes <= 1_000_000:
+            txt = subprocess.run([os.path.join(ROOT, "bin", "kmc-genfasta"), "--bytes", str(nbytes), "--seed", "7"], capture_output=True, check=True).stdout
+            assert len(txt) == exact and txt.count(b">") == n
+    # the reference's fixture shape: 200 records -> 87,492 bytes
+    assert kmc.synth_records_for_bytes(s, 87_492) == (200, 87_492)
+
+
+def test_table_formatting(kmc):
+    t = kmc.Table(np.array([0, 0], np.uint64), np.array([0b0001, 0b1110], np.uint64), np.array([2, 1], np.uint64), 2)
+    assert t.to_bytes() == b"AC\t2\nTG\t1\n"
+    assert t.to_bytes(expand=True) == b"AC\nAC\nTG\n"
+    assert t.n_total == 3

@@ -1,0 +1,229 @@
+"""GPU parity: the HIP path, called through the C ABI, against the CPU oracle (bit-exact --
+integer work), the committed golden fixtures, and size-independent properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SAMPLE
+
+pytestmark = pytest.mark.gpu
+
+KAT = json.load(open(os.path.join(GOLDEN, "kat.json")))["cases"]
+LR = json.load(open(os.path.join(GOLDEN, "lr_goldens.json")))["cases"]
+
+
+def _algos(kmc, k):
+    return [kmc.ALGO_STREAM, kmc.ALGO_AUTO]
+
+
+def _count(kmc, bases, offs, k, canonical=True, algo=0, **kw):
+    with kmc.KmerCounter(k=k, canonical=canonical, algo=algo, **kw) as kc:
+        kc.add_batch(bases, offs)
+        t = kc.export()
+        st = kc.stats()
+    return t, st
+
+
+def _random_reads(rng, n_reads, lo, hi, alphabet=b"ACGT", p_bad=0.0):
+    lens = rng.integers(lo, hi + 1, n_reads)
+    offs = np.zeros(n_reads + 1, np.uint64)
+    offs[1:] = np.cumsum(lens)
+    n = int(offs[-1])
+    bases = np.frombuffer(alphabet, np.uint8)[rng.integers(0, len(alphabet), n)].copy()
+    if p_bad > 0 and n:
+        bad = rng.random(n) < p_bad
+        bases[bad] = np.frombuffer(b"NnacgtRY-*", np.uint8)[rng.integers(0, 10, int(bad.sum()))]
+    return bases, offs
+
+
+@pytest.mark.parametrize("k", ["5", "21", "31", "63"])
+def test_sample_fasta_kats(kmc, oracle, k):
+    """configs[0] plus the KAT table: reference fixture, k = 5/21/31/63, both strands."""
+    kat = KAT[k]
+    bases, offs = kmc.parse_fasta(SAMPLE)
+    for canonical, tag in ((True, "canon"), (False, "fwd")):
+        want = oracle.count_kmers(bases, offs, int(k), canonical)
+        for algo in _algos(kmc, int(k)):
+            t, st = _count(kmc, bases, offs, int(k), canonical, algo)
+            assert t.n_total == kat["total"] and t.n_distinct == kat[f"distinct_{tag}"]
+            assert int(t.count.max()) == kat[f"max_{tag}"]
+            assert t.digest()[:16] == kat[f"digest_{tag}"]
+            assert t.equals(want)
+            assert st.n_kmers == kat["total"] and st.n_reads == 200 and st.n_bases == 80000
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 7, 11, 15, 16, 17, 24, 30, 31, 32, 33, 40, 47, 48, 49, 62, 63])
+def test_every_key_width_boundary(kmc, oracle, k):
+    rng = np.random.default_rng(100 + k)
+    bases, offs = _random_reads(rng, 300, 0, 300)
+    for canonical in (True, False):
+        want = oracle.count_kmers(bases, offs, k, canonical)
+        for algo in _algos(kmc, k):
+            t, _ = _count(kmc, bases, offs, k, canonical, algo)
+            assert t.equals(want), (k, canonical, algo)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_ragged_reads_and_invalid_bytes(kmc, oracle, seed):
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([5, 13, 21, 31, 33, 63]))
+    bases, offs = _random_reads(rng, int(rng.integers(1, 2000)), 0, int(rng.choice([40, 150, 700, 3000])), p_bad=float(rng.choice([0, 0.001, 0.02])))
+    for canonical in (True, False):
+        want = oracle.count_kmers(bases, offs, k, canonical)
+        for algo in _algos(kmc, k):
+            t, _ = _count(kmc, bases, offs, k, canonical, algo)
+            assert t.equals(want), (seed, k, canonical, algo)
+
+
+def test_low_complexity_and_palindromes(kmc, oracle):
+    # homopolymers, dinucleotide repeats (revcomp-palindromic k-mers, canonical ties), all-T reads
+    reads = [b"A" * 500, b"T" * 500, b"AT" * 300, b"ACGT" * 200, b"G" * 31, b"C" * 30, b"TTTTTTTTTT" * 7]
+    bases = np.frombuffer(b"".join(reads), np.uint8)
+    offs = np.cumsum([0] + [len(r) for r in reads]).astype(np.uint64)
+    for k in (4, 16, 31, 32, 63):
+        for canonical in (True, False):
+            want = oracle.count_kmers(bases, offs, k, canonical)
+            for algo in _algos(kmc, k):
+                t, _ = _count(kmc, bases, offs, k, canonical, algo)
+                assert t.equals(want), (k, canonical, algo)
+
+
+def test_edge_inputs(kmc, oracle):
+    z = np.zeros(0, np.uint8)
+    for k in (5, 31, 63):
+        # no reads at all; only empty reads; reads shorter than k; exactly k
+        for bases, offs in [(z, np.array([0], np.uint64)), (z, np.array([0, 0, 0], np.uint64)),
+                            (np.frombuffer(b"ACGT", np.uint8), np.array([0, 2, 4], np.uint64)),
+                            (np.frombuffer(b"ACGTTGCAAC" * 7, np.uint8)[:k], np.array([0, k], np.uint64))]:
+            want = oracle.count_kmers(bases, offs, k, True)
+            for algo in _algos(kmc, k):
+                t, _ = _count(kmc, bases, offs, k, True, algo)
+                assert t.equals(want)
+    # one long read crossing many 1024-base chunks, read starts at every alignment of a chunk edge
+    rng = np.random.default_rng(9)
+    for cut in (1023, 1024, 1025, 1024 * 3 - 30, 1024 * 3 + 31):
+        bases, _ = _random_reads(rng, 1, 5000, 5000)
+        offs = np.array([0, cut, 5000], np.uint64)
+        for k in (31, 63):
+            want = oracle.count_kmers(bases, offs, k, True)
+            t, _ = _count(kmc, bases, offs, k, True, kmc.ALGO_STREAM)
+            assert t.equals(want), (cut, k)
+
+
+def test_many_batches_and_reset(kmc, oracle):
+    rng = np.random.default_rng(3)
+    bases, offs = _random_reads(rng, 3000, 50, 400)
+    want = oracle.count_kmers(bases, offs, 21, True)
+    with kmc.KmerCounter(k=21) as kc:
+        # feed in 7 batches cut at read boundaries: counting is additive (shard invariance)
+        cuts = np.linspace(0, 3000, 8).astype(int)
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            o = offs[a:b + 1] - offs[a]
+            kc.add_batch(bases[int(offs[a]):int(offs[b])], o)
+        t = kc.export()
+        assert t.equals(want)
+        assert kc.stats().n_batches == 7
+        kc.reset()
+        assert kc.export().n_distinct == 0
+        kc.add_batch(bases, offs)
+        assert kc.export().equals(want)
+
+
+def test_high_cardinality_growth_and_spill(kmc, oracle):
+    """More distinct keys than the initial table: growth + spill path stays exact."""
+    rng = np.random.default_rng(11)
+    bases, offs = _random_reads(rng, 20000, 600, 600)   # 12 M bases, ~11.4 M distinct 31-mers
+    want = oracle.count_kmers(bases, offs, 31, True, method=1)
+    t, st = _count(kmc, bases, offs, 31, True, kmc.ALGO_STREAM)
+    assert t.equals(want)
+    assert st.table_capacity >= 2 * want.n_distinct
+
+
+def test_device_resident_batches_and_synth(kmc, oracle):
+    torch = pytest.importorskip("torch")
+    s = kmc.Synth(seed=5)
+    n = 5000
+    hb, ho = kmc.synth_reads_host(s, 100, n)
+    d_b = torch.empty(n * 400 + 64, dtype=torch.uint8, device="cuda")
+    d_o = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    kmc.synth_reads_device(s, 100, n, d_b.data_ptr(), d_o.data_ptr())
+    assert np.array_equal(d_b[:n * 400].cpu().numpy(), hb) and np.array_equal(d_o.cpu().numpy().astype(np.uint64), ho)
+    for k in (21, 31, 63):
+        want = oracle.count_kmers(hb, ho, k, True)
+        for algo in _algos(kmc, k):
+            with kmc.KmerCounter(k=k, algo=algo) as kc:
+                kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, n * 400, 400)
+                assert kc.export().equals(want)
+                kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, n * 400, 0)  # max_read_len unknown
+                t2 = kc.export()
+                assert np.array_equal(t2.count, want.count * 2) and np.array_equal(t2.key_lo, want.key_lo)
+
+
+def test_merge_and_partition(kmc, oracle):
+    """Multi-GPU reduce building blocks on one GPU: owner partition + merge == counting everything."""
+    rng = np.random.default_rng(21)
+    for k in (21, 63):
+        bases, offs = _random_reads(rng, 2000, 100, 300)
+        half = 1000
+        want = oracle.count_kmers(bases, offs, k, True)
+        with kmc.KmerCounter(k=k) as a, kmc.KmerCounter(k=k) as b, kmc.KmerCounter(k=k) as c:
+            a.add_batch(bases[:int(offs[half])], offs[:half + 1])
+            b.add_batch(bases[int(offs[half]):], offs[half:] - offs[half])
+            a.finalize(); b.finalize()
+            for src in (a, b):
+                pb, dhi, dlo, dcnt = src.partition_device(4)
+                assert pb[0] == 0 and pb[4] == src.export_device()[3]
+                # every pair sits in its owner's range
+                t = src.export()
+                own = np.array([kmc.owner_of(int(h), int(l), 4) for h, l in zip(t.key_hi[:200], t.key_lo[:200])])
+                assert own.min() >= 0 and own.max() < 4
+                for p in range(4):
+                    n = pb[p + 1] - pb[p]
+                    if n:
+                        c.merge_pairs_device((dhi + 8 * pb[p]) if dhi else 0, dlo + 8 * pb[p], dcnt + 8 * pb[p], n)
+            assert c.export().equals(want)
+
+
+def test_full_size_properties(kmc):
+    """Size-independent checks at a size the oracle would not finish quickly: totals are
+    analytic, sortedness, shard invariance, doubling the input doubles every count."""
+    torch = pytest.importorskip("torch")
+    s = kmc.Synth(seed=2)
+    n = 2_000_000  # 0.8 G bases
+    d_b = torch.empty(n * 400 + 64, dtype=torch.uint8, device="cuda")
+    d_o = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    kmc.synth_reads_device(s, 0, n, d_b.data_ptr(), d_o.data_ptr())
+    for k in (31, 63):
+        tabs = []
+        for algo in _algos(kmc, k):
+            with kmc.KmerCounter(k=k, algo=algo) as kc:
+                kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, n * 400, 400)
+                t = kc.export()
+                assert t.n_total == n * (400 - k + 1)
+                keys = (t.key_hi.astype(object) << 64) | t.key_lo.astype(object)
+                assert all(keys[i] < keys[i + 1] for i in range(len(keys) - 1))
+                assert t.n_distinct <= 10 * (81 - k) + 100 * (k - 1)
+                tabs.append(t)
+                # two shards == one batch
+                kc.reset()
+                h = n // 2
+                kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), h, h * 400, 400)
+                d_o2 = (d_o[h:] - d_o[h]).contiguous()
+                kc.add_batch_device(d_b.data_ptr() + h * 400, d_o2.data_ptr(), n - h, (n - h) * 400, 400)
+                assert kc.export().equals(t)
+        assert all(tabs[0].equals(x) for x in tabs[1:])
+
+
+def test_cli_matches_oracle(kmc, oracle, tmp_path):
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "bin", "k-mer-count")
+    for args in (["-k", "5"], ["-k", "31", "--forward"], ["-k", "21", "--expand"]):
+        out = subprocess.run([exe, SAMPLE] + args, capture_output=True, check=True).stdout
+        oargs = ["count", SAMPLE, args[1]] + [a for a in args[2:]]
+        ref = subprocess.run([oracle.ORACLE_CLI] + oargs, capture_output=True, check=True).stdout
+        assert out == ref, args
+    r = subprocess.run([exe, str(tmp_path / "missing.fasta"), "-k", "5"], capture_output=True)
+    assert r.returncode == 101 and r.stdout == b"" and b"Error during opening the file" in r.stderr

@@ -1,0 +1,120 @@
+"""The CPU oracle against every golden the reference's own files provide.
+
+LR goldens = digests of the reference's test.py output (tests/golden/lr_goldens.json);
+KATs = contiguous-k known answers on the reference's fixture (tests/golden/kat.json).
+"""
+import hashlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, SAMPLE
+
+LR = json.load(open(os.path.join(GOLDEN, "lr_goldens.json")))["cases"]
+KAT = json.load(open(os.path.join(GOLDEN, "kat.json")))["cases"]
+
+
+def _head(tmp_path, n):
+    p = tmp_path / f"head{n}.fasta"
+    with open(SAMPLE, "rb") as f:
+        lines = f.readlines()[:n]
+    p.write_bytes(b"".join(lines))
+    return str(p)
+
+
+def test_sample_fixture_is_the_references_file():
+    assert hashlib.sha256(open(SAMPLE, "rb").read()).hexdigest() == LR["G-full"]["input_sha256"]
+
+
+@pytest.mark.parametrize("case", ["G-1", "G-3", "G-full"])
+def test_lr_mode_matches_reference_output_digest(oracle, tmp_path, case):
+    g = LR[case]
+    path = SAMPLE if g["head_lines"] is None else _head(tmp_path, g["head_lines"])
+    if "input_bytes" in g:
+        assert os.path.getsize(path) == g["input_bytes"]
+    # the CLI writes exactly what main.rs:88-90 prints
+    out = subprocess.run([oracle.ORACLE_CLI, "lr", path], capture_output=True, check=True).stdout
+    assert len(out) == g["bytes"]
+    assert out.count(b"\n") == g["lines"]
+    assert hashlib.sha256(out).hexdigest() == g["sha256"]
+    # and the table view agrees with `uniq -c` of that output
+    bases, offs = oracle.parse_fasta(path)
+    t = oracle.count_lr(bases, offs)
+    assert t.klen == 54
+    assert t.n_distinct == g["distinct"] and t.n_total == g["lines"] and int(t.count.max()) == g["max_count"]
+    assert t.digest(expand=True) == g["sha256"]
+    if case == "G-full":
+        km = t.kmers()
+        assert km[0].tobytes().decode() == g["first_line"] and km[-1].tobytes().decode() == g["last_line"]
+        assert int(t.count[0]) == g["first_count"]
+        assert km[int(t.count.argmax())].tobytes().decode() == g["max_key"]
+        # `LC_ALL=C uniq -c` text: right-aligned count in 7 columns, space, key
+        h = hashlib.sha256()
+        for i in range(t.n_distinct):
+            h.update(b"%7d %s\n" % (int(t.count[i]), km[i].tobytes()))
+        assert h.hexdigest() == g["uniq_c_sha256"]
+
+
+def test_lr_empty_input(oracle, tmp_path):
+    # G-empty: header-only FASTA -> no chunks (test.py prints a lone newline; main.rs:35 panics)
+    p = tmp_path / "e.fasta"
+    p.write_bytes(b">only_header\n")
+    bases, offs = oracle.parse_fasta(str(p))
+    assert offs.tolist() == [0, 0]
+    t = oracle.count_lr(bases, offs)
+    assert t.n_distinct == 0 and t.n_total == 0
+
+
+@pytest.mark.parametrize("k", ["5", "21", "31", "63"])
+def test_contiguous_kats(oracle, k):
+    kat = KAT[k]
+    bases, offs = oracle.parse_fasta(SAMPLE)
+    for canonical, tag in ((True, "canon"), (False, "fwd")):
+        t = oracle.count_kmers(bases, offs, int(k), canonical)
+        assert t.n_total == kat["total"]
+        assert t.n_distinct == kat[f"distinct_{tag}"]
+        assert int(t.count.max()) == kat[f"max_{tag}"]
+        assert t.digest()[:16] == kat[f"digest_{tag}"]
+        if canonical and "top_canon" in kat:
+            assert t.kmers()[int(t.count.argmax())].tobytes().decode() == kat["top_canon"]
+        # the three oracle methods (sort / hash map / string materialisation) agree
+        assert t.equals(oracle.count_kmers(bases, offs, int(k), canonical, method=1))
+        assert t.equals(oracle.count_kmers_strings(bases, offs, int(k), canonical))
+
+
+def test_lr_rejects_non_acgt(oracle):
+    bases = np.frombuffer(b"ACGT" * 30 + b"N" + b"ACGT" * 30, dtype=np.uint8)
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.count_lr(bases, np.array([0, bases.size], np.uint64))
+    assert e.value.code == -3  # main.rs:23 panics
+
+
+def test_contiguous_semantics_small(oracle):
+    # windows never span records (main.rs:73-75); non-ACGT restarts the window; lower case is non-ACGT
+    bases = np.frombuffer(b"ACGTA" + b"CC" + b"GGNTTaAAC", dtype=np.uint8)
+    offs = np.array([0, 5, 7, 16], np.uint64)
+    t = oracle.count_kmers(bases, offs, 3, canonical=False)
+    got = {k.tobytes().decode(): int(c) for k, c in zip(t.kmers(), t.count)}
+    assert got == {"ACG": 1, "CGT": 1, "GTA": 1, "AAC": 1}
+    t = oracle.count_kmers(bases, offs, 2, canonical=True)
+    got = {k.tobytes().decode(): int(c) for k, c in zip(t.kmers(), t.count)}
+    # fwd: AC CG GT TA | CC | GG TT AA AC ; canonical: AC,CG,AC(GT),TA | CC(GG is rc of CC) ...
+    assert got == {"AC": 3, "CG": 1, "TA": 1, "CC": 2, "AA": 2}
+
+
+def test_parser_semantics(oracle, tmp_path):
+    p = tmp_path / "p.fasta"
+    p.write_bytes(b">r1 desc\nACGT  \r\nAC\n\n>r2\n>r3\nGG")
+    bases, offs = oracle.parse_fasta(str(p))
+    assert bases.tobytes() == b"ACGTACGG" and offs.tolist() == [0, 6, 6, 8]
+    q = tmp_path / "q.fasta"
+    q.write_bytes(b"ACGT\n")
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.parse_fasta(str(q))
+    assert e.value.code == -2
+    with pytest.raises(oracle.OracleError) as e:
+        oracle.parse_fasta(str(tmp_path / "missing.fasta"))
+    assert e.value.code == -1
