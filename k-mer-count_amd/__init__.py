@@ -102,6 +102,14 @@ def lib() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: run `make -C {_HERE}` (or __graft_entry__.build()); "
                           "there is no CPU fallback")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64/libhsa with the
+    # same SONAMEs as /opt/rocm.  Importing torch first makes libkmc.so bind to the runtime torch
+    # uses, so device pointers of torch tensors are valid inside libkmc (and torch still sees the
+    # GPU); loading libkmc first would pin the system runtime and torch then finds no device.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
     pu64 = C.POINTER(C.c_uint64)

@@ -66,6 +66,7 @@ struct kmc_ctx {
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     kmc_stats st{};
+    bool timed = false;    // ev0/ev1 bracket a finished batch
     bool pending = false;  // a batch has been queued since the last counter poll
     double rho_max = 0.0;  // largest observed (new distinct) / (k-mers) over a sub-batch
     int n_cu = 256;
@@ -190,6 +191,7 @@ int grow_to(kmc_ctx* c, u64 newcap) {
 int settle(kmc_ctx* c) {
     for (int iter = 0; iter < 40; ++iter) {
         u64 occ = c->h_counters[KMC_CTR_OCCUPIED], spill = c->h_counters[KMC_CTR_SPILL], err = c->h_counters[KMC_CTR_ERR];
+        if (err & 2) return fail(c, KMC_ERR_HIP, "table insert gave up after too many retries (internal error)");
         if (err) return fail(c, KMC_ERR_CAPACITY, "count table and spill area exhausted (capacity %llu slots, %llu spilled); raise capacity_hint",
                              (unsigned long long)c->tab.cap, (unsigned long long)spill);
         if (!spill && occ * 2 <= c->tab.cap) return KMC_OK;
@@ -333,6 +335,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
         }
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    c->timed = true;
     return KMC_OK;
 }
 
@@ -561,7 +564,11 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
     c->st.n_distinct = n;
     c->st.n_kmers = n ? c->h_counters[KMC_CTR_SUM] : 0;
     float ms = 0.f;
-    if (c->st.n_batches && hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->st.kernel_ms_last = ms;
+    if (c->timed) {
+        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) { c->st.kernel_ms_last = ms; c->st.kernel_ms_total += ms; }
+        else (void)hipGetLastError();
+        c->timed = false;
+    }
     if (n_distinct) *n_distinct = n;
     if (n_total) *n_total = c->st.n_kmers;
     return KMC_OK;

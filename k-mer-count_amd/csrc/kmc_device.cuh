@@ -76,50 +76,63 @@ __device__ __forceinline__ void kmc_spill(const GTable& g, u64 hi, u64 lo, u64 c
 
 // Add `cnt` occurrences of key (hi,lo) to the global table.  Lock-free; any number of
 // workgroups on any XCD may call it concurrently (device-scope atomics only).
-// Every iteration of the retry loop is a flat if/else chain with no inner spin, so a lane that
-// finds a slot LOCKED by another lane of its own wave simply comes round again after that lane
-// has published -- no intra-wave deadlock.
+//
+// Control flow: ONE loop whose only back-edge is taken on a wave-uniform ballot.  Every active
+// lane runs the body once per trip, so a lane that wins a slot (CAS EMPTY->LOCKED) publishes it
+// in the same trip, before any sibling lane that saw LOCKED looks again.  A per-lane
+// `while (!done)` with a "look again" path must not be used here: the compiler may split that
+// path off into an inner spin loop, and a lane spinning on a slot held by a masked-off lane of
+// its own wave never terminates.
 template <int KW>
 __device__ __forceinline__ void gtable_add(const GTable& g, u64 hi, u64 lo, u64 cnt) {
     u64 h = kmc_hash_key<KW>(hi, lo) & g.capmask;
     u64 probes = 0;
     const u64 max_probes = g.capmask < 4095 ? g.capmask + 1 : 4096;
     bool done = false;
-    while (!done) {
-        if (KW == 1) {
-            u64 cur = ld_relaxed(&g.key_lo[h]);
-            if (cur == KMC_EMPTY64) {
-                cur = atomicCAS((unsigned long long*)&g.key_lo[h], KMC_EMPTY64, lo);
-                if (cur == KMC_EMPTY64) {
-                    atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
-                    cur = lo;
-                }
-            }
-            if (cur == lo) {
-                atomicAdd((unsigned long long*)&g.count[h], cnt);
+    u32 trips = 0;
+    while (__builtin_amdgcn_ballot_w64(!done) != 0) {
+        if (!done) {
+            bool advance = false;
+            if (++trips > (1u << 22)) {  // every wave must drain: give up loudly, never spin forever
+                atomicOr((unsigned long long*)&g.counters[KMC_CTR_ERR], 2ull);
                 done = true;
-            } else {
-                h = (h + 1) & g.capmask;
-                if (++probes >= max_probes) { kmc_spill(g, hi, lo, cnt); done = true; }
-            }
-        } else {
-            u64 cur = __hip_atomic_load(&g.key_hi[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-            if (cur == KMC_EMPTY64) {
-                u64 old = atomicCAS((unsigned long long*)&g.key_hi[h], KMC_EMPTY64, KMC_LOCKED64);
-                if (old == KMC_EMPTY64) {
-                    __hip_atomic_store(&g.key_lo[h], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(&g.key_hi[h], hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                    atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
+            } else if (KW == 1) {
+                u64 cur = ld_relaxed(&g.key_lo[h]);
+                if (cur == KMC_EMPTY64) {
+                    cur = atomicCAS((unsigned long long*)&g.key_lo[h], KMC_EMPTY64, lo);
+                    if (cur == KMC_EMPTY64) {
+                        atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
+                        cur = lo;
+                    }
+                }
+                if (cur == lo) {
                     atomicAdd((unsigned long long*)&g.count[h], cnt);
                     done = true;
+                } else {
+                    advance = true;
                 }
-                // else: somebody else owns it now; look again next iteration
-            } else if (cur == KMC_LOCKED64) {
-                // being published; look again next iteration
-            } else if (cur == hi && ld_relaxed(&g.key_lo[h]) == lo) {
-                atomicAdd((unsigned long long*)&g.count[h], cnt);
-                done = true;
             } else {
+                u64 cur = __hip_atomic_load(&g.key_hi[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                if (cur == KMC_EMPTY64) {
+                    u64 old = atomicCAS((unsigned long long*)&g.key_hi[h], KMC_EMPTY64, KMC_LOCKED64);
+                    if (old == KMC_EMPTY64) {
+                        __hip_atomic_store(&g.key_lo[h], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(&g.key_hi[h], hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                        atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
+                        atomicAdd((unsigned long long*)&g.count[h], cnt);
+                        done = true;
+                    }
+                    // lost the race: the slot is LOCKED or published now; examine it next trip
+                } else if (cur == KMC_LOCKED64) {
+                    // being published by another lane/wave; examine it next trip
+                } else if (cur == hi && ld_relaxed(&g.key_lo[h]) == lo) {
+                    atomicAdd((unsigned long long*)&g.count[h], cnt);
+                    done = true;
+                } else {
+                    advance = true;
+                }
+            }
+            if (advance) {
                 h = (h + 1) & g.capmask;
                 if (++probes >= max_probes) { kmc_spill(g, hi, lo, cnt); done = true; }
             }

@@ -35,44 +35,49 @@ template <int KW> struct StreamLds {
 };
 
 // insert-or-increment in the workgroup's LDS table; falls through to the global table when the
-// probe budget is exhausted or the table is (nearly) full.
+// probe budget is exhausted or the table is (nearly) full.  Same wave-uniform loop shape as
+// gtable_add (see there for why).
 template <int KW>
 __device__ __forceinline__ void lds_add(StreamLds<KW>& L, const GTable& g, u64 hi, u64 lo, bool lds_ok) {
     constexpr u32 M = StreamLds<KW>::LCAP - 1;
     u32 h = kmc_hash32<KW>(hi, lo) & M;
     int probes = lds_ok ? 0 : 1000;
-    bool done = false;
-    while (!done) {
-        if (probes >= 24) {
-            gtable_add<KW>(g, hi, lo, 1);
-            done = true;
-        } else if (KW == 1) {
-            u64 cur = __hip_atomic_load(&L.lo[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (cur == KMC_EMPTY64) {
-                cur = atomicCAS((unsigned long long*)&L.lo[h], KMC_EMPTY64, lo);
-                if (cur == KMC_EMPTY64) { atomicAdd(&L.nfill, 1u); cur = lo; }
-            }
-            if (cur == lo) { atomicAdd(&L.cnt[h], 1u); done = true; }
-            else { h = (h + 1) & M; probes++; }
-        } else {
-            u64 cur = __hip_atomic_load(&L.hi[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (cur == KMC_EMPTY64) {
-                u64 old = atomicCAS((unsigned long long*)&L.hi[h], KMC_EMPTY64, KMC_LOCKED64);
-                if (old == KMC_EMPTY64) {
-                    __hip_atomic_store(&L.lo[h], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    __hip_atomic_store(&L.hi[h], hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    atomicAdd(&L.nfill, 1u);
+    bool done = false, to_global = false;
+    u32 trips = 0;
+    while (__builtin_amdgcn_ballot_w64(!done) != 0) {
+        if (!done) {
+            if (probes >= 24 || ++trips > (1u << 20)) {
+                to_global = true;
+                done = true;
+            } else if (KW == 1) {
+                u64 cur = __hip_atomic_load(&L.lo[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == KMC_EMPTY64) {
+                    cur = atomicCAS((unsigned long long*)&L.lo[h], KMC_EMPTY64, lo);
+                    if (cur == KMC_EMPTY64) { atomicAdd(&L.nfill, 1u); cur = lo; }
+                }
+                if (cur == lo) { atomicAdd(&L.cnt[h], 1u); done = true; }
+                else { h = (h + 1) & M; probes++; }
+            } else {
+                u64 cur = __hip_atomic_load(&L.hi[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == KMC_EMPTY64) {
+                    u64 old = atomicCAS((unsigned long long*)&L.hi[h], KMC_EMPTY64, KMC_LOCKED64);
+                    if (old == KMC_EMPTY64) {
+                        __hip_atomic_store(&L.lo[h], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(&L.hi[h], hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        atomicAdd(&L.nfill, 1u);
+                        atomicAdd(&L.cnt[h], 1u);
+                        done = true;
+                    }
+                } else if (cur == KMC_LOCKED64) {
+                    // being published; examine it next trip
+                } else if (cur == hi && __hip_atomic_load(&L.lo[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == lo) {
                     atomicAdd(&L.cnt[h], 1u);
                     done = true;
-                }
-            } else if (cur == KMC_LOCKED64) {
-                // being published by another lane; retry
-            } else if (cur == hi && __hip_atomic_load(&L.lo[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == lo) {
-                atomicAdd(&L.cnt[h], 1u);
-                done = true;
-            } else { h = (h + 1) & M; probes++; }
+                } else { h = (h + 1) & M; probes++; }
+            }
         }
     }
+    if (to_global) gtable_add<KW>(g, hi, lo, 1);
 }
 
 // wide bit masks for the validity smear: 64 bits cover the 48-base window of KW==1,
