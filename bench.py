@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- whole-job k-mer counting throughput on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N == 1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json config 3, the one the metric is quoted on): the parsed form of a
+10 GB synthetic FASTA with the distribution of the reference's random_fasta_generator.py:5-15
+(seeded re-creation, kmc_synth_*), k = 31, canonical, resident in HBM before the timed region.
+One "step" = one pass of the hot path over the resident batch: reset the count table, count
+every k-mer (HIP kernel), compact + sort the table on the device; with N > 1 also the RCCL
+count-table reduce.  Weak scaling: every rank holds its own 10 GB-equivalent shard (different
+records of the same seeded stream), no data-path collective while counting.
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant (count) kernel: algorithmic
+bytes per launch (n_bases + 8*(n_reads+1)) / its hipEvent-measured duration,
+against the 8 TB/s HBM peak.  `cpu_baseline` times the CPU oracle (a port of the reference's
+algorithm; the Rust reference cannot be built here) on a bounded sample, rank 0 at N=1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.1-6.3 TB/s is achievable
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--k", type=int, default=31)
+    ap.add_argument("--fasta-bytes", type=float, default=10e9, help="size of the synthetic FASTA text per GPU")
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--pool", type=int, default=10)
+    ap.add_argument("--algo", default="auto", choices=["auto", "stream", "walk"])
+    ap.add_argument("--forward", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-records", type=int, default=250_000)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    kmc = importlib.import_module("k-mer-count_amd")
+    kdist = importlib.import_module("k-mer-count_amd.distributed")
+    kmc.lib()  # fail loudly if the HIP extension is missing
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- resident input: this rank's shard of the seeded record stream -------------------------
+    synth = kmc.Synth(seed=args.seed, pool=args.pool)
+    n_rec, fasta_bytes = kmc.synth_records_for_bytes(synth, int(args.fasta_bytes))
+    first = rank * n_rec
+    read_len = synth.read_len
+    n_bases = n_rec * read_len
+    d_bases = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
+    d_offs = torch.empty(n_rec + 1, dtype=torch.int64, device=dev)
+    kmc.synth_reads_device(synth, first, n_rec, d_bases.data_ptr(), d_offs.data_ptr(), device=local_rank)
+    torch.cuda.synchronize()
+    k = args.k
+    n_kmers = n_rec * (read_len - k + 1)
+    algo = {"auto": kmc.ALGO_AUTO, "stream": kmc.ALGO_STREAM, "walk": kmc.ALGO_WALK}[args.algo]
+
+    kc = kmc.KmerCounter(k=k, canonical=not args.forward, device=local_rank, algo=algo)
+    owner = kmc.KmerCounter(k=k, canonical=not args.forward, device=local_rank) if world > 1 else None
+
+    kernel_ms, launches = [], []
+
+    def step(record):
+        kc.reset()
+        kc.add_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), n_rec, n_bases, read_len)
+        nd, nt = kc.finalize()
+        if nt != n_kmers:
+            raise SystemExit(f"count mismatch: table sums to {nt}, expected {n_kmers}")
+        if record:
+            st = kc.stats()
+            kernel_ms.append(st.kernel_ms_last)
+            launches.append(st.launches_last)
+        if world > 1:
+            owner.reset()
+            kdist.reduce_tables(kc, owner)
+        return nd
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nd = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = kc.stats()
+    algo_used = {1: "stream", 2: "walk"}.get(st.algo_last, "?")
+
+    # ---- roofline of the dominant kernel (this rank's launches; every rank runs the same shape) --
+    algo_bytes = n_bases + 8 * (n_rec + 1)  # 1 B/base ASCII + the offsets array
+    k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
+    achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+    traffic = None
+    prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(prof):
+        try:
+            pj = json.load(open(prof))
+            if pj.get("workload_bases") == n_bases and pj.get("k") == k and pj.get("algo") == algo_used:
+                traffic = pj.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": f"kmc_{algo_used}_kernel", "kernel_ms": round(k_ms, 4),
+                "launches_per_step": int(round(float(np.mean(launches)))) if launches else None,
+                "algorithmic_bytes_per_step": algo_bytes}
+
+    # ---- CPU baseline: the oracle (port of the reference's algorithm), bounded sample ----------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_py  # the checker/baseline, never the product
+        ns = min(args.cpu_sample_records, n_rec)
+        hb, ho = kmc.synth_reads_host(synth, first, ns)
+        tc = time.perf_counter()
+        want = oracle_py.count_kmers(hb, ho, k, canonical=not args.forward, method=1)
+        cpu_s = time.perf_counter() - tc
+        with kmc.KmerCounter(k=k, canonical=not args.forward, device=local_rank, algo=algo) as kv:
+            kv.add_batch(hb, ho)
+            exact = bool(kv.export().equals(want))
+        cpu = {"value": round(want.n_total / cpu_s, 1), "unit": "k-mers/s", "cores": 1, "kind": "port",
+               "sample": f"first {ns} records ({ns * read_len} bases) of the same workload; oracle hash-map counter "
+                         f"(2-bit rolling encode + canonical + open addressing), {cpu_s:.2f} s",
+               "gpu_bit_exact_on_sample": exact}
+        if not exact:
+            raise SystemExit("GPU table differs from the CPU oracle on the baseline sample")
+
+    if rank == 0:
+        total_kmers = n_kmers * world * args.steps
+        out = {
+            "metric": "k-mers/sec (whole node) on synthetic FASTA, k=%d; counts bit-exact vs ref" % k,
+            "value": round(total_kmers / elapsed, 1),
+            "unit": "k-mers/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u64",
+            "data": "synthetic",
+            "config": {"workload": "%.0f GB synthetic FASTA (random_fasta_generator.py distribution, seed %d, pool %d), "
+                                   "k=%d, %s, %dxMI355X" % (fasta_bytes / 1e9, args.seed, args.pool, k,
+                                                            "forward" if args.forward else "canonical", world),
+                       "records_per_gpu": n_rec, "bases_per_gpu": n_bases, "kmers_per_gpu": n_kmers,
+                       "distinct": int(nd), "algo": algo_used, "sharding": "records, one shard per GPU; RCCL all-to-all table reduce"
+                       if world > 1 else "single GPU"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

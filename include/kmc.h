@@ -87,10 +87,10 @@ typedef struct kmc_stats {
     uint64_t table_capacity;  /* slots */
     uint64_t n_spilled;       /* pairs that went through the spill area */
     uint64_t n_batches;
-    double   kernel_ms_last;  /* hipEvent time of the count kernel(s) of the last batch */
+    double   kernel_ms_last;  /* sum of hipEvent-bracketed count-kernel launches of the last batch */
     double   kernel_ms_total;
     int32_t  algo_last;       /* kmc_algo actually used for the last batch */
-    int32_t  reserved;
+    int32_t  launches_last;   /* count-kernel launches in the last batch */
 } kmc_stats;
 
 const char* kmc_version(void);

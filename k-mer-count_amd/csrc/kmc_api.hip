@@ -64,10 +64,15 @@ struct kmc_ctx {
     // walk-kernel workspace
     DevBuf walk_ws;
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the whole batch
+    std::vector<hipEvent_t> lev;              // pairs bracketing every count-kernel launch of the batch
+    size_t lev_used = 0;
     kmc_stats st{};
     bool timed = false;    // ev0/ev1 bracket a finished batch
+    bool walk_overflowed = false;  // the last WALK batch counted >5% of its k-mers directly
+    u64 direct_seen = 0, kmers_seen = 0;
     bool pending = false;  // a batch has been queued since the last counter poll
+    double rho_last = 0.0; // same, over the most recent sub-batch
     double rho_max = 0.0;  // largest observed (new distinct) / (k-mers) over a sub-batch
     int n_cu = 256;
 };
@@ -166,6 +171,14 @@ int poll(kmc_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, KMC_CTR_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->pending = false;
+    {
+        // share of k-mers the walk kernel had to count directly since the previous poll
+        u64 d = c->h_counters[KMC_CTR_BADBASE], n = c->h_counters[KMC_CTR_KMERS];
+        u64 dd = d - c->direct_seen, dn = n - c->kmers_seen;
+        if (d >= c->direct_seen && n > c->kmers_seen && c->st.algo_last == KMC_ALGO_WALK) c->walk_overflowed = dd * 20 > dn;
+        c->direct_seen = d;
+        c->kmers_seen = n;
+    }
     return KMC_OK;
 }
 
@@ -238,18 +251,37 @@ int poll_and_settle(kmc_ctx* c) {
 
 // ---- launching the counting kernels ---------------------------------------------------------
 
+// hipEvent pair around one count-kernel launch; the sum over a batch is kmc_stats.kernel_ms_last
+int launch_begin(kmc_ctx* c) {
+    if (c->lev_used + 2 > c->lev.size()) {
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreate(&e));
+            c->lev.push_back(e);
+        }
+    }
+    HIPCHK(c, hipEventRecord(c->lev[c->lev_used], c->stream));
+    return KMC_OK;
+}
+int launch_end(kmc_ctx* c) {
+    HIPCHK(c, hipEventRecord(c->lev[c->lev_used + 1], c->stream));
+    c->lev_used += 2;
+    return KMC_OK;
+}
+
 int launch_stream(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases,
                   u64 chunk_begin, u64 chunk_end) {
     // the kernel indexes chunks from 0; a sub-range is expressed by offsetting the chunk ids
     u64 n_chunks = chunk_end - chunk_begin;
     if (!n_chunks) return KMC_OK;
-    u64 max_waves = (u64)c->n_cu * 3 * KMC_STREAM_WAVES;   // 3 workgroups per CU fit (LDS)
+    u64 max_waves = (u64)c->n_cu * 2 * KMC_STREAM_WAVES;   // one workgroup per CU is resident (LDS); 2 rounds
     u64 cpw = (n_chunks + max_waves - 1) / max_waves;
     if (cpw < 4) cpw = std::min<u64>(4, n_chunks);
     u64 waves = (n_chunks + cpw - 1) / cpw;
     int grid = (int)((waves + KMC_STREAM_WAVES - 1) / KMC_STREAM_WAVES);
     GTable g = gtable_of(c, c->tab);
     const bool canon = c->cfg.canonical != 0;
+    { int rc = launch_begin(c); if (rc) return rc; }
 #define LAUNCH_STREAM(KWV, CAN)                                                                          \
     hipLaunchKernelGGL((kmc_stream_kernel<KWV, CAN>), dim3(grid), dim3(KMC_STREAM_THREADS), 0, c->stream, \
                        d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, cpw, g)
@@ -257,7 +289,7 @@ int launch_stream(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
     else { if (canon) LAUNCH_STREAM(2, true); else LAUNCH_STREAM(2, false); }
 #undef LAUNCH_STREAM
     HIPCHK(c, hipGetLastError());
-    return KMC_OK;
+    return launch_end(c);
 }
 
 int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len) {
@@ -279,7 +311,8 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             if (rc) return rc;
             max_read_len = c->h_counters[KMC_CTR_MAXLEN];
         }
-        bool walk_ok = kmc_walk_supported(c->cfg.k, c->cfg.mode, max_read_len);
+        bool walk_ok = kmc_walk_supported(c->cfg.k, c->cfg.mode, max_read_len) && n_reads < (1ull << 32);
+        if (algo == KMC_ALGO_AUTO && c->walk_overflowed) walk_ok = false;  // high-cardinality input: memo tables do not help
         if (algo == KMC_ALGO_WALK && !walk_ok)
             return fail(c, KMC_ERR_ARG, "KMC_ALGO_WALK needs k <= %d and reads of at most %d bases (longest here: %llu)",
                         KMC_WALK_MAX_K, KMC_WALK_MAX_READ, (unsigned long long)max_read_len);
@@ -288,18 +321,27 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     c->st.algo_last = algo;
 
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    c->lev_used = 0;
     int rc = KMC_OK;
     if (c->cfg.mode == KMC_MODE_LR) {
+        rc = launch_begin(c);
+        if (rc) return rc;
         rc = kmc_lr_launch(c->stream, c->n_cu, d_bases, d_offsets, n_reads, n_bases, gtable_of(c, c->tab));
         if (rc) return fail(c, rc, "LR kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = launch_end(c);
+        if (rc) return rc;
         c->pending = true;
     } else if (algo == KMC_ALGO_WALK) {
-        size_t ws_bytes = kmc_walk_workspace_bytes(c->n_cu, c->KW);
+        size_t ws_bytes = kmc_walk_workspace_bytes(n_reads);
         rc = ensure(c, c->walk_ws, ws_bytes);
         if (rc) return rc;
+        rc = launch_begin(c);
+        if (rc) return rc;
         rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_offsets, n_reads, n_bases,
-                             max_read_len, c->walk_ws.p, gtable_of(c, c->tab));
+                             c->walk_ws.p, gtable_of(c, c->tab));
         if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+        rc = launch_end(c);
+        if (rc) return rc;
         c->pending = true;
     } else {
         // Sub-batches by chunk range.  A sub-batch of n k-mers can add at most n new keys, so the
@@ -313,7 +355,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             u64 safe = std::max<u64>(freeslots / KMC_CHUNK, 1);
             u64 take = safe;
             if (prev) {
-                double rho = std::max(c->rho_max, 1e-9);
+                double rho = std::max(c->rho_last, 1e-9);
                 double opt = (double)freeslots / (4.0 * rho) / KMC_CHUNK;
                 u64 ramp = prev * 16;
                 take = std::max<u64>(safe, (u64)std::min<double>(opt, (double)ramp));
@@ -331,6 +373,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 u64 occ_after = c->h_counters[KMC_CTR_OCCUPIED];
                 double rho = (double)(occ_after > occ_before ? occ_after - occ_before : 0) / ((double)take * KMC_CHUNK);
                 c->rho_max = std::max(c->rho_max, rho);
+                c->rho_last = rho;
             }
         }
     }
@@ -386,6 +429,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
                       &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws};
     for (DevBuf* b : bufs) free_buf(*b);
+    for (hipEvent_t e : c->lev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -458,6 +502,7 @@ extern "C" int kmc_reset(kmc_ctx* c) {
     c->pending = false;
     c->sorted_valid = false;
     c->n_sorted = 0;
+    c->direct_seen = c->kmers_seen = 0;
     u64 cap = c->st.table_capacity;
     c->st = kmc_stats{};
     c->st.table_capacity = cap;
@@ -565,8 +610,15 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
     c->st.n_kmers = n ? c->h_counters[KMC_CTR_SUM] : 0;
     float ms = 0.f;
     if (c->timed) {
-        if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) { c->st.kernel_ms_last = ms; c->st.kernel_ms_total += ms; }
-        else (void)hipGetLastError();
+        // kernel time = sum over this batch's count-kernel launches (host polls between
+        // sub-batches are not kernel time); batch_ms brackets everything
+        double sum = 0.0;
+        for (size_t i = 0; i + 1 < c->lev_used; i += 2) {
+            if (hipEventElapsedTime(&ms, c->lev[i], c->lev[i + 1]) == hipSuccess) sum += ms; else (void)hipGetLastError();
+        }
+        c->st.kernel_ms_last = sum;
+        c->st.kernel_ms_total += sum;
+        c->st.launches_last = (int32_t)(c->lev_used / 2);  // launches in the last batch
         c->timed = false;
     }
     if (n_distinct) *n_distinct = n;

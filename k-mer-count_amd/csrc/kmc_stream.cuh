@@ -21,12 +21,12 @@
 #pragma once
 #include "kmc_device.cuh"
 
-#define KMC_STREAM_THREADS 512
+#define KMC_STREAM_THREADS 1024
 #define KMC_STREAM_WAVES (KMC_STREAM_THREADS / 64)
 #define KMC_CHUNK 1024
 
 template <int KW> struct StreamLds {
-    static constexpr int LCAP = (KW == 1) ? 4096 : 2048;
+    static constexpr int LCAP = (KW == 1) ? 8192 : 4096;  // 96 KB / 80 KB of keys+counts: one workgroup per CU
     u64 lo[LCAP];
     u64 hi[KW == 2 ? LCAP : 1];
     u32 cnt[LCAP];
@@ -247,7 +247,7 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         Yp[NW] = 0;
                     }
                     const bool lds_ok = __hip_atomic_load(&L.nfill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
-                                        (u32)(StreamLds<KW>::LCAP * 3 / 4);
+                                        (u32)(StreamLds<KW>::LCAP * 7 / 8);
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int s = 30 - 2 * j;

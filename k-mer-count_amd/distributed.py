@@ -1,0 +1,129 @@
+"""Multi-GPU path: one process per GPU (torch.distributed, backend "nccl" == RCCL over xGMI).
+
+Reads are independent units (a window never leaves its record, reference
+k-mer-count/src/main.rs:73-75) and counting is integer addition, so records shard across ranks
+with no data-path collective while counting.  The one real exchange step is the reduce of the
+per-GPU count tables.  Open-addressing layouts differ per GPU, so the tables are exchanged as
+(key, count) pairs: each rank partitions its sorted table by owner = mix(key) % world
+(kmc_partition_device), one all-to-all moves every partition to its owner (every GPU pair has
+its own xGMI link, so all links are busy at once), and the owner merges what it receives
+(kmc_merge_pairs_device).  The result stays partitioned by owner.
+
+The exchange itself only moves torch tensors, so the same code runs on gloo/CPU tensors in the
+world_size-2 CPU tests.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced [first, first+count) of n_items for `rank`."""
+    base, rem = divmod(n_items, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+def owner_np(key_hi: np.ndarray, key_lo: np.ndarray, n_parts: int) -> np.ndarray:
+    """Vectorised kmc_owner_of (same arithmetic as kmc_table.cuh:kmc_owner)."""
+    with np.errstate(over="ignore"):
+        z = key_lo.astype(np.uint64) ^ (key_hi.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        return (((z >> np.uint64(32)) * np.uint64(n_parts)) >> np.uint64(32)).astype(np.int64)
+
+
+class _DevArray:
+    """Zero-copy view of library-owned device memory for torch.as_tensor()."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<i8", "data": (ptr, False), "version": 3, "strides": None}
+
+
+def device_view(ptr: int, n: int, device) -> torch.Tensor:
+    """int64 torch view of n 64-bit words at device address ptr (bits are what matter)."""
+    if n == 0 or not ptr:
+        return torch.empty(0, dtype=torch.int64, device=device)
+    return torch.as_tensor(_DevArray(ptr, n), device=device)
+
+
+def all_to_all_v(send: Sequence[torch.Tensor], group=None) -> List[torch.Tensor]:
+    """Variable-size all-to-all of 1-D int64 tensors: send[p] goes to rank p; returns what each
+    rank sent here.  RCCL: one all_to_all_single for the sizes and one for the payload.  Gloo has
+    no all-to-all, so there the same exchange is written as point-to-point sends."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    dev = send[0].device
+    sizes_out = torch.tensor([int(t.numel()) for t in send], dtype=torch.int64, device=dev)
+    backend = dist.get_backend(group)
+    if backend == "nccl":
+        sizes_in = torch.empty_like(sizes_out)
+        dist.all_to_all_single(sizes_in, sizes_out, group=group)
+        in_splits = [int(x) for x in sizes_in.tolist()]
+        out_splits = [int(x) for x in sizes_out.tolist()]
+        payload = torch.cat(list(send)) if sum(out_splits) else torch.empty(0, dtype=torch.int64, device=dev)
+        recv = torch.empty(sum(in_splits), dtype=torch.int64, device=dev)
+        dist.all_to_all_single(recv, payload, output_split_sizes=in_splits, input_split_sizes=out_splits, group=group)
+        return list(torch.split(recv, in_splits))
+    gathered = [torch.empty_like(sizes_out) for _ in range(world)]
+    dist.all_gather(gathered, sizes_out, group=group)
+    in_splits = [int(g[rank]) for g in gathered]
+    recv = [torch.empty(n, dtype=torch.int64, device=dev) for n in in_splits]
+    recv[rank].copy_(send[rank])
+    ops = []
+    for p in range(world):
+        if p == rank:
+            continue
+        if send[p].numel():
+            ops.append(dist.P2POp(dist.isend, send[p].contiguous(), p, group))
+        if in_splits[p]:
+            ops.append(dist.P2POp(dist.irecv, recv[p], p, group))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return recv
+
+
+def exchange_pairs(parts_hi: Optional[Sequence[torch.Tensor]], parts_lo: Sequence[torch.Tensor],
+                   parts_cnt: Sequence[torch.Tensor], group=None):
+    """Send partition p of (hi, lo, cnt) to rank p.  Returns per-source lists (hi may be None)."""
+    recv_lo = all_to_all_v(parts_lo, group)
+    recv_cnt = all_to_all_v(parts_cnt, group)
+    recv_hi = all_to_all_v(parts_hi, group) if parts_hi is not None else None
+    return recv_hi, recv_lo, recv_cnt
+
+
+def reduce_tables(local, owner, group=None):
+    """The RCCL count-table reduce.  `local`: KmerCounter holding this rank's counts;
+    `owner`: a second (reset) KmerCounter on the same GPU that receives the keys this rank owns.
+    Afterwards owner.export() is this rank's partition of the global table.
+    Returns (pairs_sent, pairs_received)."""
+    world = dist.get_world_size(group)
+    dev = torch.device("cuda", local.device)
+    local.finalize()
+    pb, d_hi, d_lo, d_cnt = local.partition_device(world)
+    n = pb[world]
+    lo = device_view(d_lo, n, dev)
+    cnt = device_view(d_cnt, n, dev)
+    hi = device_view(d_hi, n, dev) if d_hi else None
+    cut = lambda t: [t[pb[p]:pb[p + 1]] for p in range(world)]
+    recv_hi, recv_lo, recv_cnt = exchange_pairs(cut(hi) if hi is not None else None, cut(lo), cut(cnt), group)
+    got = 0
+    keep = []  # keep the received tensors alive until the merge kernels have run
+    for p in range(world):
+        m = int(recv_lo[p].numel())
+        if not m:
+            continue
+        rl, rc = recv_lo[p].contiguous(), recv_cnt[p].contiguous()
+        rh = recv_hi[p].contiguous() if recv_hi is not None else None
+        keep.append((rl, rc, rh))
+        torch.cuda.current_stream(dev).synchronize()  # payload landed before the ctx stream reads it
+        owner.merge_pairs_device(rh.data_ptr() if rh is not None else 0, rl.data_ptr(), rc.data_ptr(), m)
+        got += m
+    owner.finalize()
+    return n, got

@@ -14,8 +14,16 @@ KAT = json.load(open(os.path.join(GOLDEN, "kat.json")))["cases"]
 LR = json.load(open(os.path.join(GOLDEN, "lr_goldens.json")))["cases"]
 
 
-def _algos(kmc, k):
-    return [kmc.ALGO_STREAM, kmc.ALGO_AUTO]
+def _algos(kmc, k, max_read_len=None):
+    """Every algorithm that can take this input (WALK: k <= 31 and reads <= 416 bases)."""
+    a = [kmc.ALGO_STREAM, kmc.ALGO_AUTO]
+    if k <= 31 and (max_read_len is None or 1 <= max_read_len <= 416):
+        a.append(kmc.ALGO_WALK)
+    return a
+
+
+def _maxlen(offs):
+    return int(np.diff(offs.astype(np.int64)).max()) if len(offs) > 1 else 0
 
 
 def _count(kmc, bases, offs, k, canonical=True, algo=0, **kw):
@@ -45,7 +53,7 @@ def test_sample_fasta_kats(kmc, oracle, k):
     bases, offs = kmc.parse_fasta(SAMPLE)
     for canonical, tag in ((True, "canon"), (False, "fwd")):
         want = oracle.count_kmers(bases, offs, int(k), canonical)
-        for algo in _algos(kmc, int(k)):
+        for algo in _algos(kmc, int(k), 400):
             t, st = _count(kmc, bases, offs, int(k), canonical, algo)
             assert t.n_total == kat["total"] and t.n_distinct == kat[f"distinct_{tag}"]
             assert int(t.count.max()) == kat[f"max_{tag}"]
@@ -60,7 +68,7 @@ def test_every_key_width_boundary(kmc, oracle, k):
     bases, offs = _random_reads(rng, 300, 0, 300)
     for canonical in (True, False):
         want = oracle.count_kmers(bases, offs, k, canonical)
-        for algo in _algos(kmc, k):
+        for algo in _algos(kmc, k, _maxlen(offs)):
             t, _ = _count(kmc, bases, offs, k, canonical, algo)
             assert t.equals(want), (k, canonical, algo)
 
@@ -72,9 +80,31 @@ def test_ragged_reads_and_invalid_bytes(kmc, oracle, seed):
     bases, offs = _random_reads(rng, int(rng.integers(1, 2000)), 0, int(rng.choice([40, 150, 700, 3000])), p_bad=float(rng.choice([0, 0.001, 0.02])))
     for canonical in (True, False):
         want = oracle.count_kmers(bases, offs, k, canonical)
-        for algo in _algos(kmc, k):
+        for algo in _algos(kmc, k, _maxlen(offs)):
             t, _ = _count(kmc, bases, offs, k, canonical, algo)
             assert t.equals(want), (seed, k, canonical, algo)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_walk_short_reads(kmc, oracle, seed):
+    """KMC_ALGO_WALK on its own ground: ragged short reads (0..416), non-ACGT bytes (diverted to the
+    scalar kernel), pool-like low cardinality and full-random high cardinality (memo overflow ->
+    direct counting), every step-tail length."""
+    rng = np.random.default_rng(200 + seed)
+    for k in (3, 8, 9, 21, 31):
+        hi = int(rng.choice([20, 100, 250, 416]))
+        bases, offs = _random_reads(rng, int(rng.integers(1, 6000)), 0, hi, p_bad=float(rng.choice([0, 0.002])))
+        if seed % 2 == 0:
+            # low cardinality: rebuild the reads from a pool of 7 lines of 40 bases
+            pool = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (7, 40))]
+            n = int(offs[-1])
+            picks = rng.integers(0, 7, n // 40 + 2)
+            bases = pool[picks].reshape(-1)[:n].copy()
+        for canonical in (True, False):
+            want = oracle.count_kmers(bases, offs, k, canonical)
+            t, st = _count(kmc, bases, offs, k, canonical, kmc.ALGO_WALK)
+            assert st.algo_last == kmc.ALGO_WALK
+            assert t.equals(want), (seed, k, hi, canonical)
 
 
 def test_low_complexity_and_palindromes(kmc, oracle):
@@ -85,7 +115,7 @@ def test_low_complexity_and_palindromes(kmc, oracle):
     for k in (4, 16, 31, 32, 63):
         for canonical in (True, False):
             want = oracle.count_kmers(bases, offs, k, canonical)
-            for algo in _algos(kmc, k):
+            for algo in _algos(kmc, k, _maxlen(offs)):
                 t, _ = _count(kmc, bases, offs, k, canonical, algo)
                 assert t.equals(want), (k, canonical, algo)
 
@@ -152,10 +182,10 @@ def test_device_resident_batches_and_synth(kmc, oracle):
     assert np.array_equal(d_b[:n * 400].cpu().numpy(), hb) and np.array_equal(d_o.cpu().numpy().astype(np.uint64), ho)
     for k in (21, 31, 63):
         want = oracle.count_kmers(hb, ho, k, True)
-        for algo in _algos(kmc, k):
+        for algo in _algos(kmc, k, 400):
             with kmc.KmerCounter(k=k, algo=algo) as kc:
                 kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, n * 400, 400)
-                assert kc.export().equals(want)
+                assert kc.export().equals(want), (k, algo)
                 kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, n * 400, 0)  # max_read_len unknown
                 t2 = kc.export()
                 assert np.array_equal(t2.count, want.count * 2) and np.array_equal(t2.key_lo, want.key_lo)
@@ -197,7 +227,7 @@ def test_full_size_properties(kmc):
     kmc.synth_reads_device(s, 0, n, d_b.data_ptr(), d_o.data_ptr())
     for k in (31, 63):
         tabs = []
-        for algo in _algos(kmc, k):
+        for algo in _algos(kmc, k, 400):
             with kmc.KmerCounter(k=k, algo=algo) as kc:
                 kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, n * 400, 400)
                 t = kc.export()
