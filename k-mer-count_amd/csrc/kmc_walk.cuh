@@ -2,18 +2,20 @@
 //
 // Replaces the reference's window loop + grouping (k-mer-count/src/main.rs:63-87) for
 // contiguous k, exactly (same table as KMC_ALGO_STREAM and the CPU oracle), with ONE LDS lookup
-// per 8 bases instead of one hash-table update per k-mer.
+// per 16 bases instead of one hash-table update per k-mer.
 //
 // Idea.  Counting k-mers of a read is a walk in the de Bruijn graph of the input.  Each
-// workgroup keeps, in LDS, a memo of that walk at a stride of 8 bases:
+// workgroup keeps, in LDS, a memo of that walk at a stride of 16 bases:
 //   node  = a context: the last k bases (a k-mer), or -- within the first k bases of a read --
-//           the whole prefix read so far (depths 0, 8, 16, ...).  Reads start at ROOT.
-//   edge  = (node, next <=8 bases) -> successor node, plus a 32-bit traversal counter.
-// A lane owns one read and advances 8 bases per step: key = node|label, one ds_read_b64 of the
-// edge entry, one ds_add on its counter, successor comes back with the entry.  No k-mer is
-// formed, hashed or compared on this path.  The first time an edge is seen (slow path) the
+//           the whole prefix read so far (depths 0, 16, ...).  Reads start at ROOT.
+//   edge  = (node, next <=16 bases) -> successor node, plus a 32-bit traversal counter.  The
+//           first continuation seen after a node is its PRIMARY edge and lives inside the node
+//           entry (direct-indexed, no hashing); other continuations go to a hashed edge table.
+// A lane owns one read and advances 16 bases per step: one ds_read_b64 of the node's
+// {label, successor}, one compare with the read's next 16 bases, one ds_add on the counter.  No
+// k-mer is formed, hashed or compared on this path.  The first time an edge is seen (slow path) the
 // successor context is built from the node's stored key and inserted with LDS CAS.  At the end
-// of the kernel every edge is unfolded once: its <=8 k-mers (those at depth >= k) each receive
+// of the kernel every edge is unfolded once: its <=16 k-mers (those at depth >= k) each receive
 // the edge's counter in the global table (canonical strand chosen there, once per distinct
 // k-mer instead of once per occurrence).  Counting is additive, so the result is bit-identical
 // to per-occurrence counting.  When a memo table is full the lane counts its k-mers directly
@@ -34,24 +36,35 @@
 #define KMC_WALK_WAVES 16
 #define KMC_WALK_THREADS (KMC_WALK_WAVES * 64)
 #define KMC_WALK_STAGE_WORDS (64 * KMC_WALK_MAX_READ / 16 + 4)
-#define KMC_WALK_ELOG 11
+#define KMC_WALK_STRIDE 16
+#define KMC_WALK_ELOG 10
 #define KMC_WALK_ECAP (1 << KMC_WALK_ELOG)
-#define KMC_WALK_NLOG 11
+#define KMC_WALK_NLOG 10
 #define KMC_WALK_NCAP (1 << KMC_WALK_NLOG)
-#define KMC_WALK_DIRECT_ID 8190u  // node-id field of a lane that counts directly (never allocated)
-#define KMC_WALK_EMPTY_KEY 0xFFFFFFFFu
 #define KMC_WALK_BADWORDS 64
 
-struct WalkEdge {
-    u64 kv;   // low 32: key = label(16) | (len-1)<<16 | node<<19 ; high 32: successor, pre-shifted (node<<19 | 7<<16)
-    u32 cnt;  // traversals
+// A node and its PRIMARY out-edge (the first 16-base continuation seen after this context),
+// direct-indexed by node id: the hot step is one ds_read_b64 of {plabel, psucc} + one ds_add.
+struct WalkNode {
+    u64 prim;  // low 32: label = 16 bases, 2 bits each, first base in the low bits (internal code
+               // A0 C1 T2 G3); high 32: byte offset (id*16) of the successor node, 0 = no primary yet
+    u32 cnt;   // traversals of the primary edge
     u32 pad;
 };
+// Secondary edges (other continuations, and the <16-base step that ends a read): hashed.
+// kv = label(32) | (len-1)<<32 (4 bits) | node<<36 (11 bits) | succ<<47 (11 bits); ~0 = empty
+struct WalkEdge {
+    u64 kv;
+    u32 cnt;
+    u32 pad;
+};
+#define KMC_EDGE_KEYMASK ((1ull << 47) - 1)
 
 struct WalkLds {
     u32 stage[KMC_WALK_WAVES][KMC_WALK_STAGE_WORDS];
-    WalkEdge edge[KMC_WALK_ECAP];
+    WalkNode node[KMC_WALK_NCAP];  // node 0 is never allocated: state 0 = "count directly"
     u64 nkeys[KMC_WALK_NCAP];
+    WalkEdge edge[KMC_WALK_ECAP];
     u32 badbits[KMC_WALK_WAVES][KMC_WALK_BADWORDS];
     u32 nedges, nnodes;
 };
@@ -62,8 +75,8 @@ struct WalkWs {
     unsigned long long pad[7];
 };
 
-// node keys: k-mer nodes hold the 2k-bit context (top bits clear); prefix nodes (depth < k, read
-// start) hold  1<<63 | depth<<56 | 2*depth bits
+// node keys: k-mer nodes hold the 2k-bit context in the public coding A0 C1 G2 T3 (top bits
+// clear); prefix nodes (depth < k, read start) hold  1<<63 | depth<<56 | 2*depth bits
 #define KMC_NODE_PREFIX (1ull << 63)
 __device__ __forceinline__ u64 node_encode(u64 ctx, u32 depth, int k, u64 mask) {
     return depth >= (u32)k ? (ctx & mask) : (KMC_NODE_PREFIX | ((u64)depth << 56) | ctx);
@@ -85,10 +98,29 @@ __device__ __forceinline__ void walk_gadd(const GTable& g, u64 kmer, int k, u64 
     gtable_add<1>(g, 0ull, key, cnt);
 }
 
-// find-or-insert a node key; returns its id or 0xFFFFFFFF when the node table is full
+// Extend a context by `len` bases of a label (internal code -> public code: c ^ (c>>1)).
+// COUNT: every k-mer completed on the way receives `cnt` in the global table.
+template <bool CANON, bool COUNT>
+__device__ __forceinline__ u64 walk_roll(const GTable& g, u64& ctx, u32& depth, u32 label, int len, int k, u64 mask, u64 cnt) {
+    u64 n = 0;
+    for (int t = 0; t < len; ++t) {
+        u32 c = (label >> (2 * t)) & 3u;
+        c ^= c >> 1;
+        ctx = (ctx << 2) | c;
+        if (depth < (u32)k) depth++;
+        if (depth >= (u32)k) {
+            ctx &= mask;
+            if (COUNT) { walk_gadd<CANON>(g, ctx, k, cnt); n++; }
+        }
+    }
+    return n;
+}
+
+// find-or-insert a node key; returns its id (>= 1) or 0 when the node table is full
 __device__ __forceinline__ u32 walk_node(WalkLds& L, u64 nk) {
     u32 h = (u32)(kmc_mix64(nk) >> (64 - KMC_WALK_NLOG));
-    u32 res = 0xFFFFFFFFu;
+    if (h == 0) h = 1;
+    u32 res = 0;
     bool done = false;
     int probes = 0;
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
@@ -104,71 +136,81 @@ __device__ __forceinline__ u32 walk_node(WalkLds& L, u64 nk) {
             }
             if (!done) {
                 if (cur == nk) { res = h; done = true; }
-                else { h = (h + 1) & (KMC_WALK_NCAP - 1); if (++probes > 64) done = true; }
+                else {
+                    h = (h + 1) & (KMC_WALK_NCAP - 1);
+                    if (h == 0) h = 1;
+                    if (++probes > 64) done = true;
+                }
             }
         }
     }
     return res;
 }
 
-// Slow path of one step: the edge (key) was not found at its home slot.
-// Returns the lane's next state word.  dctx/ddepth: context of a lane in direct mode.
+// Slow path of one step from node offset `s` (s == 0: direct mode).  Returns the next state.
 template <bool CANON>
-__device__ __forceinline__ u32 walk_slow(WalkLds& L, const GTable& g, u32 key, u32 h, int len, int k, u64 mask,
-                                      u64& dctx, u32& ddepth, u64& ndirect) {
-    const u32 label = key & 0xFFFFu;
-    const u32 s = key >> 19;
-    if (s == KMC_WALK_DIRECT_ID) {
-        // direct mode: roll the context and count every k-mer with a global atomic
-        for (int t = 0; t < len; ++t) {
-            u32 c = (label >> (2 * t)) & 3u;
-            dctx = ((dctx << 2) | c) & mask;
-            if (ddepth < (u32)k) ddepth++;
-            if (ddepth >= (u32)k) { walk_gadd<CANON>(g, dctx, k, 1); ndirect++; }
-        }
-        return (KMC_WALK_DIRECT_ID << 19) | (7u << 16);
+__device__ __forceinline__ u32 walk_slow(WalkLds& L, const GTable& g, u32 s, u32 label, int len, int k, u64 mask,
+                                         u64& dctx, u32& ddepth, u64& ndirect) {
+    if (s == 0) {  // direct mode: roll the context and count every k-mer with a global atomic
+        ndirect += walk_roll<CANON, true>(g, dctx, ddepth, label, len, k, mask, 1);
+        return 0;
     }
-    // 1. probe for the edge / an empty slot
-    u32 hh = h;
-    bool done = false, found = false, have_val = false;
-    u32 val = 0;
+    const u32 id = s >> 4;
+    // successor context (needed to create an edge) -- built once, lazily
+    bool have_succ = false;
+    u32 sid = 0;  // successor node id, 0 = none / table full
     u64 sctx = 0;
     u32 sdepth = 0;
+    auto make_succ = [&]() {
+        node_decode(__hip_atomic_load(&L.nkeys[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), k, sctx, sdepth);
+        (void)walk_roll<CANON, false>(g, sctx, sdepth, label, len, k, mask, 0);
+        sid = (len == KMC_WALK_STRIDE) ? walk_node(L, node_encode(sctx, sdepth, k, mask)) : 0;
+        have_succ = true;
+    };
+    WalkNode* np = reinterpret_cast<WalkNode*>(reinterpret_cast<char*>(L.node) + s);
+    u64* pp = &np->prim;
+    if (len == KMC_WALK_STRIDE) {
+        // 1. the node's primary edge
+        u64 pe = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if ((u32)(pe >> 32) == 0) {
+            make_succ();
+            if (sid) {
+                u64 want = (u64)label | ((u64)(sid << 4) << 32);
+                u64 old = atomicCAS((unsigned long long*)pp, 0ull, want);
+                pe = old == 0 ? want : old;
+            }
+        }
+        if ((u32)pe == label && (u32)(pe >> 32) != 0) {
+            atomicAdd(&np->cnt, 1u);
+            return (u32)(pe >> 32);
+        }
+    }
+    // 2. secondary edge: hashed
+    const u64 key = (u64)label | ((u64)(len - 1) << 32) | ((u64)id << 36);
+    u32 hh = (u32)(kmc_mix64(key) >> (64 - KMC_WALK_ELOG));
+    bool done = false, found = false;
+    u32 val = 0;
     int probes = 0;
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
         if (!done) {
             u64 kv = __hip_atomic_load(&L.edge[hh].kv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((u32)kv == key) {
+            if (((kv ^ key) & KMC_EDGE_KEYMASK) == 0 && kv != ~0ull) {
                 atomicAdd(&L.edge[hh].cnt, 1u);
-                val = (u32)(kv >> 32);
+                val = (u32)(kv >> 47);
                 found = true;
                 done = true;
-            } else if ((u32)kv == KMC_WALK_EMPTY_KEY) {
-                if (!have_val) {
-                    // successor context = node context extended by the label
-                    node_decode(__hip_atomic_load(&L.nkeys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), k, sctx, sdepth);
-                    for (int t = 0; t < len; ++t) {
-                        u32 c = (label >> (2 * t)) & 3u;
-                        sctx = (sctx << 2) | c;
-                        if (sdepth < (u32)k) sdepth++;
-                        if (sdepth >= (u32)k) sctx &= mask;
-                    }
-                    if (len == 8) {
-                        u32 id = walk_node(L, node_encode(sctx, sdepth, k, mask));
-                        val = id == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((id << 19) | (7u << 16));
-                    } else {
-                        val = 0;  // a partial step ends the read: no successor needed
-                    }
-                    have_val = true;
-                }
-                if (val == 0xFFFFFFFFu || __hip_atomic_load(&L.nedges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (u32)(KMC_WALK_ECAP * 3 / 4)) {
+            } else if (kv == ~0ull) {
+                if (!have_succ) make_succ();
+                if ((len == KMC_WALK_STRIDE && sid == 0) ||
+                    __hip_atomic_load(&L.nedges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (u32)(KMC_WALK_ECAP * 3 / 4)) {
                     done = true;  // memo full
                 } else {
-                    u64 want = (u64)key | ((u64)val << 32);
+                    u64 want = key | ((u64)sid << 47);
                     u64 old = atomicCAS((unsigned long long*)&L.edge[hh].kv, ~0ull, want);
                     if (old == ~0ull) {
                         atomicAdd(&L.nedges, 1u);
                         atomicAdd(&L.edge[hh].cnt, 1u);
+                        val = sid;
                         found = true;
                         done = true;
                     }
@@ -180,39 +222,37 @@ __device__ __forceinline__ u32 walk_slow(WalkLds& L, const GTable& g, u32 key, u
             }
         }
     }
-    if (found) return val;
-    // 2. memo full: count this step's k-mers directly from the node's context
+    if (found) return val << 4;  // (a <16-base step ends the read; its successor is unused)
+    // 3. memo full: count this step's k-mers directly from the node's context
     u64 ctx;
     u32 depth;
-    node_decode(__hip_atomic_load(&L.nkeys[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), k, ctx, depth);
-    for (int t = 0; t < len; ++t) {
-        u32 c = (label >> (2 * t)) & 3u;
-        ctx = (ctx << 2) | c;
-        if (depth < (u32)k) depth++;
-        if (depth >= (u32)k) { ctx &= mask; walk_gadd<CANON>(g, ctx, k, 1); ndirect++; }
-    }
-    if (len != 8) return 0;
-    if (!have_val) {
-        u32 id = walk_node(L, node_encode(ctx, depth, k, mask));
-        val = id == 0xFFFFFFFFu ? 0xFFFFFFFFu : ((id << 19) | (7u << 16));
-    }
-    if (val != 0xFFFFFFFFu) return val;  // successor node exists: stay on the memoised path
+    node_decode(__hip_atomic_load(&L.nkeys[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), k, ctx, depth);
+    ndirect += walk_roll<CANON, true>(g, ctx, depth, label, len, k, mask, 1);
+    if (len != KMC_WALK_STRIDE) return 0;
+    if (!have_succ) make_succ();
+    if (sid) return sid << 4;  // successor node exists: stay on the memoised path
     dctx = ctx;
     ddepth = depth;
-    return (KMC_WALK_DIRECT_ID << 19) | (7u << 16);
+    return 0;  // direct mode from here on
 }
 
-template <bool CANON>
-__device__ __forceinline__ u32 walk_step(WalkLds& L, const GTable& g, u32 sk, u32 label, int len, int k, u64 mask,
-                                         u64& dctx, u32& ddepth, u64& ndirect) {
-    const u32 key = (len == 8) ? (sk | label) : ((sk & ~(7u << 16)) | ((u32)(len - 1) << 16) | (label & ((1u << (2 * len)) - 1u)));
-    const u32 h = (key * 0x9E3779B1u) >> (32 - KMC_WALK_ELOG);
-    const u64 kv = __hip_atomic_load(&L.edge[h].kv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if ((u32)kv == key) {
-        atomicAdd(&L.edge[h].cnt, 1u);
-        return (u32)(kv >> 32);
-    }
-    return walk_slow<CANON>(L, g, key, h, len, k, mask, dctx, ddepth, ndirect);
+// 16 ASCII bases -> one 32-bit word, 2 bits per base, first base in the low bits, internal code
+// A0 C1 T2 G3 = (byte>>1)&3 (no G/T fix-up on the hot path; walk_roll converts).  xany != 0 iff a
+// byte is not one of "ACGT" (v_perm_b32 as an 8-entry LUT: selectors 4..7 read 0x00).
+__device__ __forceinline__ u32 walk_encode16(uint4 v, u32& x0, u32& x1, u32& x2, u32& x3) {
+    const u32 s0 = (v.x >> 1) & 0x07070707u, s1 = (v.y >> 1) & 0x07070707u;
+    const u32 s2 = (v.z >> 1) & 0x07070707u, s3 = (v.w >> 1) & 0x07070707u;
+    x0 = v.x ^ __builtin_amdgcn_perm(0u, 0x47544341u, s0);
+    x1 = v.y ^ __builtin_amdgcn_perm(0u, 0x47544341u, s1);
+    x2 = v.z ^ __builtin_amdgcn_perm(0u, 0x47544341u, s2);
+    x3 = v.w ^ __builtin_amdgcn_perm(0u, 0x47544341u, s3);
+    // byte j of u = bases j, 4+j, 8+j, 12+j (2 bits each): a 4x4 transpose away from base order
+    u32 u = s0 | (s1 << 2) | (s2 << 4) | (s3 << 6);
+    u32 t = ((u >> 12) ^ u) & 0x0000F0F0u;
+    u ^= t | (t << 12);
+    t = ((u >> 6) ^ u) & 0x00CC00CCu;
+    u ^= t | (t << 6);
+    return u;
 }
 
 template <bool CANON>
@@ -225,14 +265,18 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     const u64 mask = (1ull << (2 * k)) - 1;
 
     for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) { L.edge[i].kv = ~0ull; L.edge[i].cnt = 0; }
-    for (int i = tid; i < KMC_WALK_NCAP; i += KMC_WALK_THREADS) L.nkeys[i] = KMC_EMPTY64;
+    for (int i = tid; i < KMC_WALK_NCAP; i += KMC_WALK_THREADS) {
+        L.nkeys[i] = KMC_EMPTY64;
+        L.node[i].prim = 0; L.node[i].cnt = 0;
+    }
     if (tid == 0) { L.nedges = 0; L.nnodes = 1; }
     __syncthreads();
     const u64 root_key = KMC_NODE_PREFIX;  // prefix node of depth 0
-    const u32 root_id = (u32)(kmc_mix64(root_key) >> (64 - KMC_WALK_NLOG));
+    u32 root_id = (u32)(kmc_mix64(root_key) >> (64 - KMC_WALK_NLOG));
+    if (root_id == 0) root_id = 1;
     if (tid == 0) L.nkeys[root_id] = root_key;
     __syncthreads();
-    const u32 sk_root = (root_id << 19) | (7u << 16);
+    const u32 s_root = root_id << 4;
 
     u32* stage = L.stage[wv];
     u64 nk = 0, ndirect = 0;
@@ -266,11 +310,11 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
             for (int u = 0; u < 4; ++u) {
                 u32 p = p0 + 64 * u + lane;
                 if (p < n_pieces) {
-                    Enc16 en = encode16(v[u]);
-                    stage[p] = en.wle;
-                    if ((en.x0 | en.x1 | en.x2 | en.x3) != 0) {
+                    u32 x0, x1, x2, x3;
+                    stage[p] = walk_encode16(v[u], x0, x1, x2, x3);
+                    if ((x0 | x1 | x2 | x3) != 0) {
                         // exact check, ignoring bytes outside this wave's range [A, B)
-                        u32 bad = bad16_from(en);
+                        u32 bad = nonzero_bytes4(x0) | (nonzero_bytes4(x1) << 4) | (nonzero_bytes4(x2) << 8) | (nonzero_bytes4(x3) << 12);
                         u64 pos = A16 + 16ull * p;
                         if (pos < A) bad &= ~((1u << (u32)(A - pos)) - 1u);
                         if (pos + 16 > B) bad &= (B > pos) ? ((1u << (u32)(B - pos)) - 1u) : 0u;
@@ -307,23 +351,32 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
 
         const u32 rel = (u32)(a - A16);
         const u32 w0 = rel >> 4, sh = 2 * (rel & 15);
-        const u32 nfull = mine ? (len_read >> 3) : 0;
-        const u32 tail = mine ? (len_read & 7) : 0;
-        u32 sk = sk_root;
+        const u32 nfull = mine ? (len_read >> 4) : 0;
+        const u32 tail = mine ? (len_read & 15) : 0;
+        const u32 nsteps = nfull + (tail ? 1u : 0u);
+        u32 s = s_root;
         u64 dctx = 0;
         u32 ddepth = 0;
-        const u32 nsteps = nfull + (tail ? 1u : 0u);
-        u32 wc = mine ? stage[w0] : 0, cw = 0;
-        for (u32 t = 0; t < KMC_WALK_MAX_READ / 8 + 1; ++t) {
+        u32 wc = mine ? stage[w0] : 0;
+        for (u32 t = 0; t < KMC_WALK_MAX_READ / KMC_WALK_STRIDE + 1; ++t) {
             const bool act = t < nsteps;
             if (__builtin_amdgcn_ballot_w64(act) == 0) break;
-            if ((t & 1) == 0) {  // every second step: next 16 bases of my read, re-aligned to its start
-                u32 wn = act ? stage[w0 + (t >> 1) + 1] : 0;
-                cw = alignbit(wn, wc, sh);
+            if (act) {
+                // next 16 bases of my read, re-aligned to its start
+                const u32 wn = stage[w0 + t + 1];
+                u32 label = alignbit(wn, wc, sh);
                 wc = wn;
+                const bool full = t < nfull;
+                WalkNode* np = reinterpret_cast<WalkNode*>(reinterpret_cast<char*>(L.node) + s);
+                const u64 pe = __hip_atomic_load(&np->prim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (full && (u32)pe == label && (u32)(pe >> 32) != 0) {
+                    atomicAdd(&np->cnt, 1u);
+                    s = (u32)(pe >> 32);
+                } else {
+                    if (!full) label &= (1u << (2 * tail)) - 1u;
+                    s = walk_slow<CANON>(L, g, s, label, full ? KMC_WALK_STRIDE : (int)tail, k, mask, dctx, ddepth, ndirect);
+                }
             }
-            const u32 label = (t & 1) ? (cw >> 16) : (cw & 0xFFFFu);
-            if (act) sk = walk_step<CANON>(L, g, sk, label, t < nfull ? 8 : (int)tail, k, mask, dctx, ddepth, ndirect);
         }
         __builtin_amdgcn_wave_barrier();  // staging area is reused by the next tile
     }
@@ -336,20 +389,21 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
 
     // ---- flush: unfold every memoised edge into its k-mers ----
     __syncthreads();
-    for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) {
-        const u64 kv = L.edge[i].kv;
-        const u32 key = (u32)kv, cnt = L.edge[i].cnt;
-        if (key != KMC_WALK_EMPTY_KEY && cnt) {
-            const u32 label = key & 0xFFFFu, len = ((key >> 16) & 7u) + 1, s = key >> 19;
+    for (int i = tid; i < KMC_WALK_NCAP + KMC_WALK_ECAP; i += KMC_WALK_THREADS) {
+        u32 label, len, id, cnt;
+        if (i < KMC_WALK_NCAP) {
+            id = (u32)i; label = (u32)L.node[i].prim; len = KMC_WALK_STRIDE;
+            cnt = ((L.node[i].prim >> 32) != 0) ? L.node[i].cnt : 0;
+        } else {
+            const u64 kv = L.edge[i - KMC_WALK_NCAP].kv;
+            cnt = (kv != ~0ull) ? L.edge[i - KMC_WALK_NCAP].cnt : 0;
+            label = (u32)kv; len = ((u32)(kv >> 32) & 15u) + 1; id = (u32)(kv >> 36) & (KMC_WALK_NCAP - 1);
+        }
+        if (cnt) {
             u64 ctx;
             u32 depth;
-            node_decode(L.nkeys[s], k, ctx, depth);
-            for (u32 t = 0; t < len; ++t) {
-                u32 c = (label >> (2 * t)) & 3u;
-                ctx = (ctx << 2) | c;
-                if (depth < (u32)k) depth++;
-                if (depth >= (u32)k) { ctx &= mask; walk_gadd<CANON>(g, ctx, k, cnt); }
-            }
+            node_decode(L.nkeys[id], k, ctx, depth);
+            (void)walk_roll<CANON, true>(g, ctx, depth, label, (int)len, k, mask, cnt);
         }
     }
 }
