@@ -284,44 +284,78 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     const u64 gw = (u64)blockIdx.x * KMC_WALK_WAVES + wv;
     const u64 total_waves = (u64)gridDim.x * KMC_WALK_WAVES;
 
-    for (u64 tile = gw; tile < n_tiles; tile += total_waves) {
+    // Per-tile geometry: the wave's 64 reads are the byte range [A, B) of the batch.
+    struct TileGeo { u64 a, e, A, B, A16; u32 n_pieces; u32 have; };
+    auto tile_geo = [&](u64 tile) {
+        TileGeo t;
         const u64 r = tile * 64 + lane;
-        const bool have = r < n_reads;
-        const u64 a = offsets[have ? r : n_reads];
-        const u64 e = offsets[have ? r + 1 : n_reads];
-        const u64 A = __shfl(a, 0);
-        const u64 B = __shfl(e, 63);  // lanes past the last read hold offsets[n_reads] twice
-        const u64 A16 = A & ~15ull;
-        const u32 n_pieces = (u32)((B - A16 + 15) >> 4);
-
-        // ---- load phase: coalesced 16 B pieces -> 2-bit words in this wave's staging area ----
-        if (lane < KMC_WALK_BADWORDS) L.badbits[wv][lane] = 0;
-        bool anybad = false;
-        for (u32 p0 = 0; p0 < n_pieces; p0 += 256) {
-            uint4 v[4];
+        t.have = r < n_reads ? 1u : 0u;
+        t.a = offsets[t.have ? r : n_reads];
+        t.e = offsets[t.have ? r + 1 : n_reads];
+        t.A = __shfl(t.a, 0);
+        t.B = __shfl(t.e, 63);  // lanes past the last read hold offsets[n_reads] twice
+        t.A16 = t.A & ~15ull;
+        t.n_pieces = (u32)((t.B - t.A16 + 15) >> 4);
+        return t;
+    };
+    // Four coalesced 1 KiB wave-loads: pieces base + {0,64,128,192} + lane of the byte range that
+    // starts at A16.  Branch-free on purpose (straight-line code lets the compiler keep counted
+    // s_waitcnt vmcnt(N) and two sets in flight): a piece index past the end is clamped to the
+    // last piece -- that re-reads one cache line and is never stored.
+    auto issue4 = [&](uint4 (&v)[4], u64 A16, u32 last, u32 base) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                u32 p = p0 + 64 * u + lane;
-                u64 pos = A16 + 16ull * p;
-                v[u] = make_uint4(0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u);
-                if (p < n_pieces && pos < n_bases) v[u] = *reinterpret_cast<const uint4*>(bases + pos);
-            }
+        for (int u = 0; u < 4; ++u) {
+            u32 p = base + 64 * u + lane;
+            p = p < last ? p : last;
+            v[u] = *reinterpret_cast<const uint4*>(bases + A16 + 16ull * p);
+        }
+    };
+    bool anybad = false;
+    auto consume4 = [&](const uint4 (&v)[4], const TileGeo& t, u32 base) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                u32 p = p0 + 64 * u + lane;
-                if (p < n_pieces) {
-                    u32 x0, x1, x2, x3;
-                    stage[p] = walk_encode16(v[u], x0, x1, x2, x3);
-                    if ((x0 | x1 | x2 | x3) != 0) {
-                        // exact check, ignoring bytes outside this wave's range [A, B)
-                        u32 bad = nonzero_bytes4(x0) | (nonzero_bytes4(x1) << 4) | (nonzero_bytes4(x2) << 8) | (nonzero_bytes4(x3) << 12);
-                        u64 pos = A16 + 16ull * p;
-                        if (pos < A) bad &= ~((1u << (u32)(A - pos)) - 1u);
-                        if (pos + 16 > B) bad &= (B > pos) ? ((1u << (u32)(B - pos)) - 1u) : 0u;
-                        if (bad) { atomicOr(&L.badbits[wv][p >> 5], 1u << (p & 31)); anybad = true; }
-                    }
+        for (int u = 0; u < 4; ++u) {
+            const u32 p = base + 64 * u + lane;
+            if (p < t.n_pieces) {
+                u32 x0, x1, x2, x3;
+                stage[p] = walk_encode16(v[u], x0, x1, x2, x3);
+                if ((x0 | x1 | x2 | x3) != 0) {
+                    // exact check, ignoring bytes outside this wave's range [A, B)
+                    u32 bad = nonzero_bytes4(x0) | (nonzero_bytes4(x1) << 4) | (nonzero_bytes4(x2) << 8) | (nonzero_bytes4(x3) << 12);
+                    const u64 pos = t.A16 + 16ull * p;
+                    if (pos < t.A) bad &= ~((1u << (u32)(t.A - pos)) - 1u);
+                    if (pos + 16 > t.B) bad &= (t.B > pos) ? ((1u << (u32)(t.B - pos)) - 1u) : 0u;
+                    if (bad) { atomicOr(&L.badbits[wv][p >> 5], 1u << (p & 31)); anybad = true; }
                 }
             }
+        }
+    };
+
+    uint4 va[4], vb[4];
+    TileGeo cur;
+    if (gw < n_tiles) { cur = tile_geo(gw); issue4(va, cur.A16, cur.n_pieces ? cur.n_pieces - 1 : 0, 0); }
+    for (u64 tile = gw; tile < n_tiles; tile += total_waves) {
+        const u64 r = tile * 64 + lane;
+        const bool have = cur.have != 0;
+        const u64 a = cur.a, e = cur.e, A16 = cur.A16;
+        const u32 n_pieces = cur.n_pieces;
+        const bool has_next = tile + total_waves < n_tiles;
+        TileGeo nxt = cur;
+        if (has_next) nxt = tile_geo(tile + total_waves);
+
+        // ---- load phase: coalesced 16 B pieces -> 2-bit words in this wave's staging area.
+        // Two register sets keep 4-8 KiB per wave in flight; the round that would run past the end
+        // of this tile fetches the first round of the NEXT tile instead, so that its latency hides
+        // behind the step phase. ----
+        if (lane < KMC_WALK_BADWORDS) L.badbits[wv][lane] = 0;
+        anybad = false;
+        const u32 np_u = (u32)__builtin_amdgcn_readfirstlane((int)n_pieces);
+        const u32 cur_last = n_pieces ? n_pieces - 1 : 0, nxt_last = nxt.n_pieces ? nxt.n_pieces - 1 : 0;
+        for (u32 base = 0; base < np_u || base == 0; base += 512) {
+            issue4(vb, A16, cur_last, base + 256);
+            consume4(va, cur, base);
+            const bool more = base + 512 < np_u;  // wave-uniform
+            issue4(va, more ? A16 : nxt.A16, more ? cur_last : nxt_last, more ? base + 512 : 0u);
+            consume4(vb, cur, base + 256);
         }
         if (lane == 0) stage[n_pieces] = 0;  // the re-alignment reads one word past the last piece
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -379,6 +413,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
             }
         }
         __builtin_amdgcn_wave_barrier();  // staging area is reused by the next tile
+        cur = nxt;
     }
     nk = wave_sum_u64(nk);
     ndirect = wave_sum_u64(ndirect);
