@@ -307,7 +307,10 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         for (int u = 0; u < 4; ++u) {
             u32 p = base + 64 * u + lane;
             p = p < last ? p : last;
-            v[u] = *reinterpret_cast<const uint4*>(bases + A16 + 16ull * p);
+            // streamed once: non-temporal (nt) loads measured +4 % over the default cache policy
+            typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+            u32x4_t q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(bases + A16 + 16ull * p));
+            v[u] = make_uint4(q.x, q.y, q.z, q.w);
         }
     };
     bool anybad = false;
@@ -330,6 +333,11 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         }
     };
 
+    // A round = 256 pieces = 4 KiB per wave.  Two register sets with fixed roles (va: even rounds,
+    // vb: odd rounds) keep 4-8 KiB per wave in flight.  A tile is padded to an even number of
+    // rounds (a padding round re-reads the tile's last cache line and is never stored); the round
+    // after the padded end is round 0 of the NEXT tile, whose latency therefore hides behind this
+    // tile's step phase.  (Three sets / 12 KiB in flight measured slower: 128 VGPRs.)
     uint4 va[4], vb[4];
     TileGeo cur;
     if (gw < n_tiles) { cur = tile_geo(gw); issue4(va, cur.A16, cur.n_pieces ? cur.n_pieces - 1 : 0, 0); }
@@ -342,10 +350,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         TileGeo nxt = cur;
         if (has_next) nxt = tile_geo(tile + total_waves);
 
-        // ---- load phase: coalesced 16 B pieces -> 2-bit words in this wave's staging area.
-        // Two register sets keep 4-8 KiB per wave in flight; the round that would run past the end
-        // of this tile fetches the first round of the NEXT tile instead, so that its latency hides
-        // behind the step phase. ----
+        // ---- load phase: coalesced 16 B pieces -> 2-bit words in this wave's staging area ----
         if (lane < KMC_WALK_BADWORDS) L.badbits[wv][lane] = 0;
         anybad = false;
         const u32 np_u = (u32)__builtin_amdgcn_readfirstlane((int)n_pieces);
