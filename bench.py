@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--algo", default="auto", choices=["auto", "stream", "walk"])
     ap.add_argument("--forward", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-records", type=int, default=250_000)
+    ap.add_argument("--cpu-sample-records", type=int, default=5_000_000, help="bounded CPU-baseline sample (~10-15 s of one core)")
     args = ap.parse_args()
 
     import torch

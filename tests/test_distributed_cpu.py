@@ -1,0 +1,87 @@
+"""N > 1 path on CPU: world_size-2 `gloo` processes run the same exchange code bench.py uses
+(k-mer-count_amd/distributed.py).  The per-rank tables come from the CPU oracle here (no GPU in
+this container); on a GPU box the same functions move device tensors over RCCL."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, SAMPLE
+
+WORLD = 2
+
+
+def _merge_np(his, los, cnts):
+    """sum counts of equal (hi, lo) keys; sorted ascending (test-side reference merge)."""
+    hi = np.concatenate(his); lo = np.concatenate(los); c = np.concatenate(cnts)
+    order = np.lexsort((lo, hi))
+    hi, lo, c = hi[order], lo[order], c[order]
+    if hi.size == 0:
+        return hi, lo, c
+    new = np.ones(hi.size, bool)
+    new[1:] = (hi[1:] != hi[:-1]) | (lo[1:] != lo[:-1])
+    idx = np.cumsum(new) - 1
+    out = np.zeros(int(idx[-1]) + 1, np.uint64)
+    np.add.at(out, idx, c)
+    return hi[new], lo[new], out
+
+
+def _worker(rank, port, k, tmpdir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        kmc = importlib.import_module("k-mer-count_amd")
+        kd = importlib.import_module("k-mer-count_amd.distributed")
+        import oracle_py
+        bases, offs = oracle_py.parse_fasta(SAMPLE)
+        n_reads = len(offs) - 1
+        first, cnt = kd.shard_range(n_reads, rank, WORLD)
+        sb = bases[int(offs[first]):int(offs[first + cnt])]
+        so = offs[first:first + cnt + 1] - offs[first]
+        local = oracle_py.count_kmers(sb, so, k, True)          # this rank's shard table
+        owner = kd.owner_np(local.key_hi, local.key_lo, WORLD)
+        # same function as the library's kmc_owner_of
+        for i in range(0, local.n_distinct, max(1, local.n_distinct // 50)):
+            assert kmc.owner_of(int(local.key_hi[i]), int(local.key_lo[i]), WORLD) == int(owner[i])
+        as_t = lambda a: torch.from_numpy(a.astype(np.int64, copy=True))
+        parts = lambda a: [as_t(a[owner == p]) for p in range(WORLD)]
+        rhi, rlo, rcnt = kd.exchange_pairs(parts(local.key_hi), parts(local.key_lo), parts(local.count))
+        assert all(int(t.numel()) == int(u.numel()) for t, u in zip(rlo, rcnt))
+        to_np = lambda ts: [t.numpy().astype(np.uint64) for t in ts]
+        mhi, mlo, mcnt = _merge_np(to_np(rhi), to_np(rlo), to_np(rcnt))
+        # everything this rank now owns really is its partition
+        assert np.all(kd.owner_np(mhi, mlo, WORLD) == rank)
+        np.savez(os.path.join(tmpdir, f"owned{rank}.npz"), hi=mhi, lo=mlo, cnt=mcnt)
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k", [21, 63])
+def test_world2_reduce_equals_single_table(oracle, tmp_path, k):
+    port = 29000 + (os.getpid() + k) % 2000
+    mp.spawn(_worker, args=(port, k, str(tmp_path)), nprocs=WORLD, join=True)
+    parts = [np.load(tmp_path / f"owned{r}.npz") for r in range(WORLD)]
+    hi, lo, cnt = _merge_np([p["hi"] for p in parts], [p["lo"] for p in parts], [p["cnt"] for p in parts])
+    bases, offs = oracle.parse_fasta(SAMPLE)
+    want = oracle.count_kmers(bases, offs, k, True)
+    assert np.array_equal(hi, want.key_hi) and np.array_equal(lo, want.key_lo) and np.array_equal(cnt, want.count)
+    # partitions are disjoint: no key is owned twice
+    assert sum(len(p["lo"]) for p in parts) == want.n_distinct
+
+
+def test_shard_range_covers_everything():
+    kd = importlib.import_module("k-mer-count_amd.distributed")
+    for n in (0, 1, 7, 200, 22371032):
+        for w in (1, 2, 3, 8):
+            spans = [kd.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+            assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            assert max(c for _, c in spans) - min(c for _, c in spans) <= 1

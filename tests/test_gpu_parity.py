@@ -257,3 +257,30 @@ def test_cli_matches_oracle(kmc, oracle, tmp_path):
         assert out == ref, args
     r = subprocess.run([exe, str(tmp_path / "missing.fasta"), "-k", "5"], capture_output=True)
     assert r.returncode == 101 and r.stdout == b"" and b"Error during opening the file" in r.stderr
+
+
+def test_rccl_reduce_single_rank(kmc, oracle):
+    """The multi-GPU reduce (partition -> RCCL all-to-all -> merge) with a one-rank nccl group:
+    exercises the device plumbing bench.py --gpus N uses (zero-copy views of library memory,
+    all_to_all_single, kmc_merge_pairs_device).  More ranks need more GPUs (driver's 8-GPU run);
+    the routing logic itself is covered by the world_size-2 gloo tests."""
+    torch = pytest.importorskip("torch")
+    import importlib
+    import torch.distributed as dist
+    kd = importlib.import_module("k-mer-count_amd.distributed")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 1000))
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(77)
+        for k in (31, 63):
+            bases, offs = _random_reads(rng, 3000, 100, 400)
+            want = oracle.count_kmers(bases, offs, k, True)
+            with kmc.KmerCounter(k=k) as local, kmc.KmerCounter(k=k) as owner:
+                local.add_batch(bases, offs)
+                sent, got = kd.reduce_tables(local, owner)
+                assert sent == got == want.n_distinct
+                assert owner.export().equals(want)
+    finally:
+        dist.destroy_process_group()

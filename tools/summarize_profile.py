@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Condenses a tools/profile_bench.sh output directory (gpurun_out/prof_<tag>) into the files
+kept under profiles/: <name>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary),
+<name>_pmc.json (per-launch counter averages of the count kernel, HBM traffic with the gfx950
+FETCH_SIZE correction), and r01_pmc_traffic.json which bench.py reads for roofline.traffic.
+
+usage: tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<name> <kernel substring> bases k algo
+"""
+import collections, csv, glob, json, os, shutil, sys
+
+src, dst, kname, bases, k, algo = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+os.makedirs(os.path.dirname(dst), exist_ok=True)
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, dst + "_kernel_stats.csv")
+avg_ns = None
+for r in csv.DictReader(open(stats)):
+    if kname in r["Name"]:
+        avg_ns = float(r["AverageNs"]); calls = int(r["Calls"])
+ctr = collections.defaultdict(list)
+for f in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.csv"))):
+    for r in csv.DictReader(open(f)):
+        if kname in r["Kernel_Name"]:
+            ctr[r["Counter_Name"]].append(float(r["Counter_Value"]))
+avg = {c: sum(v) / len(v) for c, v in ctr.items()}
+# MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
+# half of the bytes of a wide coalesced streaming read (16 B/lane) -> double it; WRITE_SIZE exact.
+fetch = avg.get("FETCH_SIZE", 0) * 1024 * 2
+write = avg.get("WRITE_SIZE", 0) * 1024
+out = {"kernel": kname, "calls_traced": calls, "avg_duration_ns": avg_ns, "counters_avg_per_launch": avg,
+       "hbm_read_bytes_per_launch": fetch, "hbm_write_bytes_per_launch": write,
+       "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for 16 B/lane streams); separate --pmc passes"}
+json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
+json.dump({"workload_bases": bases, "k": k, "algo": algo, "hbm_bytes_per_launch": fetch + write,
+           "source": os.path.basename(dst) + "_pmc.json"}, open(os.path.join(os.path.dirname(dst), "r01_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])
