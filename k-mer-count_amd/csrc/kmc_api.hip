@@ -24,6 +24,7 @@
 #include "kmc_synth.cuh"
 #include "kmc_table.cuh"
 #include "kmc_walk.cuh"
+#include "kmc_lr.cuh"
 
 namespace {
 
@@ -204,6 +205,7 @@ int grow_to(kmc_ctx* c, u64 newcap) {
 int settle(kmc_ctx* c) {
     for (int iter = 0; iter < 40; ++iter) {
         u64 occ = c->h_counters[KMC_CTR_OCCUPIED], spill = c->h_counters[KMC_CTR_SPILL], err = c->h_counters[KMC_CTR_ERR];
+        if (err & 4) return fail(c, KMC_ERR_ALPHABET, "Unexpected charactor appears in a sequence (reference mode accepts ACGT only)");
         if (err & 2) return fail(c, KMC_ERR_HIP, "table insert gave up after too many retries (internal error)");
         if (err) return fail(c, KMC_ERR_CAPACITY, "count table and spill area exhausted (capacity %llu slots, %llu spilled); raise capacity_hint",
                              (unsigned long long)c->tab.cap, (unsigned long long)spill);
@@ -324,6 +326,18 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     c->lev_used = 0;
     int rc = KMC_OK;
     if (c->cfg.mode == KMC_MODE_LR) {
+        // every window start contributes up to 61 new keys: make room first (exact worst case)
+        {
+            u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
+            u64 worst = occ + n_bases * (KMC_LR_SMAX - KMC_LR_SMIN + 1);
+            if (worst * 2 > c->tab.cap) {
+                u64 want = next_pow2(worst * 2);
+                if (want > (1ull << 33)) return fail(c, KMC_ERR_CAPACITY, "LR batch too large: %llu bases need %llu table slots; feed smaller batches",
+                                                     (unsigned long long)n_bases, (unsigned long long)want);
+                rc = grow_to(c, want);
+                if (rc) return rc;
+            }
+        }
         rc = launch_begin(c);
         if (rc) return rc;
         rc = kmc_lr_launch(c->stream, c->n_cu, d_bases, d_offsets, n_reads, n_bases, gtable_of(c, c->tab));
@@ -466,8 +480,8 @@ extern "C" int kmc_create(kmc_ctx** out, const kmc_config* cfg) {
         HIPCHK(c, hipMemsetAsync(c->d_counters, 0, KMC_CTR_N * sizeof(u64), c->stream));
         HIPCHK(c, hipHostMalloc((void**)&c->h_counters, KMC_CTR_N * sizeof(u64)));
         memset(c->h_counters, 0, KMC_CTR_N * sizeof(u64));
-        u64 cap = next_pow2(std::max<u64>(cfg->capacity_hint * 2, 1ull << 22));
-        c->spill_cap = std::max<u64>(cap / 4, 1ull << 20);
+        u64 cap = next_pow2(std::max<u64>(cfg->capacity_hint * 2, 1ull << 20));
+        c->spill_cap = std::max<u64>(cap / 4, 1ull << 18);
         HIPCHK(c, hipMalloc((void**)&c->spill_lo, c->spill_cap * sizeof(u64)));
         HIPCHK(c, hipMalloc((void**)&c->spill_cnt, c->spill_cap * sizeof(u64)));
         if (c->KW == 2) HIPCHK(c, hipMalloc((void**)&c->spill_hi, c->spill_cap * sizeof(u64)));

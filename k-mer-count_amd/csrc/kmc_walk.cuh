@@ -514,4 +514,3 @@ static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool 
     return hipGetLastError() == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
 
-static inline int kmc_lr_launch(hipStream_t, int, const uint8_t*, const u64*, u64, u64, GTable) { return KMC_ERR_ARG; }

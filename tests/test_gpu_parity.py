@@ -284,3 +284,70 @@ def test_rccl_reduce_single_rank(kmc, oracle):
                 assert owner.export().equals(want)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", ["G-1", "G-3", "G-full"])
+def test_reference_mode_matches_reference_goldens(kmc, oracle, tmp_path, case):
+    """KMC_MODE_LR on the GPU reproduces the digests of the reference's OWN output
+    (test.py / main.rs:87-90 on sample.fasta), and the oracle's table."""
+    g = LR[case]
+    path = SAMPLE
+    if g["head_lines"] is not None:
+        path = str(tmp_path / "head.fasta")
+        with open(SAMPLE, "rb") as f:
+            open(path, "wb").write(b"".join(f.readlines()[:g["head_lines"]]))
+    t = kmc.count_file(path, k=None)
+    assert t.klen == 54 and t.n_distinct == g["distinct"] and t.n_total == g["lines"] and int(t.count.max()) == g["max_count"]
+    assert t.digest(expand=True) == g["sha256"]
+    bases, offs = kmc.parse_fasta(path)
+    assert t.equals(oracle.count_lr(bases, offs))
+
+
+def test_reference_mode_cli_and_errors(kmc, oracle, tmp_path):
+    import hashlib
+    import shutil
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "bin", "k-mer-count")
+    # no arguments: opens ./sample.fasta in the cwd like main.rs:44 and prints main.rs:88-90's lines
+    shutil.copy(SAMPLE, tmp_path / "sample.fasta")
+    out = subprocess.run([exe], cwd=tmp_path, capture_output=True, check=True).stdout
+    assert hashlib.sha256(out).hexdigest() == LR["G-full"]["sha256"]
+    # a non-ACGT character aborts the reference (main.rs:23): exit 101, nothing on stdout
+    bad = tmp_path / "bad.fasta"
+    bad.write_bytes(b">r\n" + b"ACGT" * 30 + b"N" + b"ACGT" * 30 + b"\n")
+    r = subprocess.run([exe, str(bad)], capture_output=True)
+    assert r.returncode == 101 and r.stdout == b"" and b"Unexpected charactor" in r.stderr
+    with kmc.KmerCounter(mode=kmc.MODE_LR) as kc:
+        b = np.frombuffer(b"ACGT" * 30 + b"N" + b"ACGT" * 30, np.uint8)
+        kc.add_batch(b, np.array([0, b.size], np.uint64))
+        with pytest.raises(kmc.KmcError) as e:
+            kc.finalize()
+        assert e.value.status == kmc.ERR_ALPHABET
+    # header-only / short records: empty result (G-empty)
+    with kmc.KmerCounter(mode=kmc.MODE_LR) as kc:
+        b = np.frombuffer(b"ACGT" * 19, np.uint8)  # 76 < 80
+        kc.add_batch(b, np.array([0, 0, b.size], np.uint64))
+        assert kc.export().n_distinct == 0
+    # ragged random records vs the oracle
+    rng = np.random.default_rng(5)
+    bases, offs = _random_reads(rng, 60, 0, 300)
+    with kmc.KmerCounter(mode=kmc.MODE_LR) as kc:
+        kc.add_batch(bases, offs)
+        assert kc.export().equals(oracle.count_lr(bases, offs))
+
+
+def test_walk_repeatability_stress(kmc, oracle):
+    """Same-size batches with different data every time through fresh contexts (freed device
+    buffers get reused) -- guards against races in the LDS memo and against stale reads."""
+    rng = np.random.default_rng(7)
+    for it in range(40):
+        k = int(rng.choice([17, 24, 31]))
+        lens = rng.integers(0, 301, 300) if it % 2 else np.full(300, 150)
+        offs = np.zeros(301, np.uint64)
+        offs[1:] = np.cumsum(lens)
+        bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(offs[-1]))].copy()
+        want = oracle.count_kmers(bases, offs, k, True)
+        for algo in (kmc.ALGO_WALK, kmc.ALGO_STREAM, kmc.ALGO_WALK):
+            t, _ = _count(kmc, bases, offs, k, True, algo)
+            assert t.equals(want), (it, k, algo)
