@@ -31,7 +31,7 @@
 #include "../../include/kmc.h"
 #include "kmc_device.cuh"
 
-#define KMC_WALK_MAX_K 31
+#define KMC_WALK_MAX_K 63
 #define KMC_WALK_MAX_READ 416
 #define KMC_WALK_WAVES 16
 #define KMC_WALK_THREADS (KMC_WALK_WAVES * 64)
@@ -60,10 +60,12 @@ struct WalkEdge {
 };
 #define KMC_EDGE_KEYMASK ((1ull << 47) - 1)
 
+template <int KW>
 struct WalkLds {
     u32 stage[KMC_WALK_WAVES][KMC_WALK_STAGE_WORDS];
     WalkNode node[KMC_WALK_NCAP];  // node 0 is never allocated: state 0 = "count directly"
-    u64 nkeys[KMC_WALK_NCAP];
+    u64 nkeys[KMC_WALK_NCAP];      // node key, low word
+    u64 nkeys_hi[KW == 2 ? KMC_WALK_NCAP : 1];  // high word (k >= 32): claimed EMPTY->LOCKED->value
     WalkEdge edge[KMC_WALK_ECAP];
     u32 badbits[KMC_WALK_WAVES][KMC_WALK_BADWORDS];
     u32 nedges, nnodes;
@@ -75,72 +77,134 @@ struct WalkWs {
     unsigned long long pad[7];
 };
 
-// node keys: k-mer nodes hold the 2k-bit context in the public coding A0 C1 G2 T3 (top bits
-// clear); prefix nodes (depth < k, read start) hold  1<<63 | depth<<56 | 2*depth bits
+// A context: up to 63 bases, 2 bits each in the public coding A0 C1 G2 T3, newest base in the low
+// bits of lo.  hi stays 0 when KW == 1 (k <= 31).
+struct WCtx { u64 hi, lo; };
+
+// node keys: k-mer nodes hold the 2k-bit context (top bits of the top word clear); prefix nodes
+// (depth < k, read start) hold  1<<63 | depth<<56  in the top word plus their 2*depth bits.
+// Top word == ~0 is EMPTY, ~0-1 is LOCKED (two-word keys while being published).
 #define KMC_NODE_PREFIX (1ull << 63)
-__device__ __forceinline__ u64 node_encode(u64 ctx, u32 depth, int k, u64 mask) {
-    return depth >= (u32)k ? (ctx & mask) : (KMC_NODE_PREFIX | ((u64)depth << 56) | ctx);
+template <int KW>
+__device__ __forceinline__ WCtx node_encode(WCtx c, u32 depth, int k, u64 mask_hi, u64 mask_lo) {
+    WCtx n;
+    if (depth >= (u32)k) { n.hi = c.hi & mask_hi; n.lo = c.lo & mask_lo; }
+    else if (KW == 1) { n.hi = 0; n.lo = KMC_NODE_PREFIX | ((u64)depth << 56) | c.lo; }
+    else { n.hi = KMC_NODE_PREFIX | ((u64)depth << 56) | c.hi; n.lo = c.lo; }
+    return n;
 }
-__device__ __forceinline__ void node_decode(u64 nk, int k, u64& ctx, u32& depth) {
-    if (nk >> 63) { depth = (u32)(nk >> 56) & 0x7Fu; ctx = nk & ((1ull << 56) - 1); }
-    else { depth = (u32)k; ctx = nk; }
+template <int KW>
+__device__ __forceinline__ void node_decode(WCtx nk, int k, WCtx& c, u32& depth) {
+    const u64 top = KW == 1 ? nk.lo : nk.hi;
+    if (top >> 63) {
+        depth = (u32)(top >> 56) & 0x7Fu;
+        if (KW == 1) { c.hi = 0; c.lo = nk.lo & ((1ull << 56) - 1); }
+        else { c.hi = nk.hi & ((1ull << 56) - 1); c.lo = nk.lo; }
+    } else {
+        depth = (u32)k;
+        c = nk;
+    }
+}
+template <int KW>
+__device__ __forceinline__ WCtx node_key_load(WalkLds<KW>& L, u32 id) {
+    WCtx n;
+    n.lo = __hip_atomic_load(&L.nkeys[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    n.hi = KW == 2 ? __hip_atomic_load(&L.nkeys_hi[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0ull;
+    return n;
 }
 
 // canonical (or forward) key of a k-mer context -> global table
-template <bool CANON>
-__device__ __forceinline__ void walk_gadd(const GTable& g, u64 kmer, int k, u64 cnt) {
-    u64 key = kmer;
+template <int KW, bool CANON>
+__device__ __forceinline__ void walk_gadd(const GTable& g, WCtx kmer, int k, u64 cnt) {
+    u64 khi = kmer.hi, klo = kmer.lo;
     if (CANON) {
         u64 rhi, rlo;
-        revcomp_key(0ull, kmer, k, rhi, rlo);
-        if (rlo < key) key = rlo;
+        revcomp_key(kmer.hi, kmer.lo, k, rhi, rlo);
+        if (key_less(rhi, rlo, khi, klo)) { khi = rhi; klo = rlo; }
     }
-    gtable_add<1>(g, 0ull, key, cnt);
+    gtable_add<KW>(g, khi, klo, cnt);
 }
 
 // Extend a context by `len` bases of a label (internal code -> public code: c ^ (c>>1)).
 // COUNT: every k-mer completed on the way receives `cnt` in the global table.
-template <bool CANON, bool COUNT>
-__device__ __forceinline__ u64 walk_roll(const GTable& g, u64& ctx, u32& depth, u32 label, int len, int k, u64 mask, u64 cnt) {
+template <int KW, bool CANON, bool COUNT>
+__device__ __forceinline__ u64 walk_roll(const GTable& g, WCtx& ctx, u32& depth, u32 label, int len, int k,
+                                         u64 mask_hi, u64 mask_lo, u64 cnt) {
     u64 n = 0;
     for (int t = 0; t < len; ++t) {
         u32 c = (label >> (2 * t)) & 3u;
         c ^= c >> 1;
-        ctx = (ctx << 2) | c;
+        if (KW == 2) ctx.hi = (ctx.hi << 2) | (ctx.lo >> 62);
+        ctx.lo = (ctx.lo << 2) | c;
         if (depth < (u32)k) depth++;
         if (depth >= (u32)k) {
-            ctx &= mask;
-            if (COUNT) { walk_gadd<CANON>(g, ctx, k, cnt); n++; }
+            ctx.lo &= mask_lo;
+            if (KW == 2) ctx.hi &= mask_hi;
+            if (COUNT) { walk_gadd<KW, CANON>(g, ctx, k, cnt); n++; }
         }
     }
     return n;
 }
 
-// find-or-insert a node key; returns its id (>= 1) or 0 when the node table is full
-__device__ __forceinline__ u32 walk_node(WalkLds& L, u64 nk) {
-    u32 h = (u32)(kmc_mix64(nk) >> (64 - KMC_WALK_NLOG));
+// find-or-insert a node key; returns its id (>= 1) or 0 when the node table is full.
+// Same wave-uniform loop shape as gtable_add (kmc_device.cuh).
+template <int KW>
+__device__ __forceinline__ u32 walk_node(WalkLds<KW>& L, WCtx nk) {
+    u32 h = (u32)(kmc_hash_key<KW>(nk.hi, nk.lo) >> (64 - KMC_WALK_NLOG));
     if (h == 0) h = 1;
     u32 res = 0;
     bool done = false;
     int probes = 0;
+    u32 trips = 0;
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
         if (!done) {
-            u64 cur = __hip_atomic_load(&L.nkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (cur == KMC_EMPTY64) {
-                if (__hip_atomic_load(&L.nnodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= (u32)(KMC_WALK_NCAP * 3 / 4)) {
-                    done = true;  // full
+            bool advance = false;
+            const bool room = __hip_atomic_load(&L.nnodes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (u32)(KMC_WALK_NCAP * 3 / 4);
+            if (++trips > (1u << 16)) {
+                done = true;  // give up (treated as "table full"): every wave must drain
+            } else if (KW == 1) {
+                u64 cur = __hip_atomic_load(&L.nkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == KMC_EMPTY64) {
+                    if (!room) {
+                        done = true;  // full
+                    } else {
+                        cur = atomicCAS((unsigned long long*)&L.nkeys[h], KMC_EMPTY64, nk.lo);
+                        if (cur == KMC_EMPTY64) { atomicAdd(&L.nnodes, 1u); cur = nk.lo; }
+                    }
+                }
+                if (!done) {
+                    if (cur == nk.lo) { res = h; done = true; }
+                    else advance = true;
+                }
+            } else {
+                u64 cur = __hip_atomic_load(&L.nkeys_hi[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == KMC_EMPTY64) {
+                    if (!room) {
+                        done = true;  // full
+                    } else {
+                        u64 old = atomicCAS((unsigned long long*)&L.nkeys_hi[h], KMC_EMPTY64, KMC_LOCKED64);
+                        if (old == KMC_EMPTY64) {
+                            __hip_atomic_store(&L.nkeys[h], nk.lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            __hip_atomic_store(&L.nkeys_hi[h], nk.hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            atomicAdd(&L.nnodes, 1u);
+                            res = h;
+                            done = true;
+                        }
+                        // lost the race: examine the slot again next trip
+                    }
+                } else if (cur == KMC_LOCKED64) {
+                    // being published; examine it again next trip
+                } else if (cur == nk.hi && __hip_atomic_load(&L.nkeys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == nk.lo) {
+                    res = h;
+                    done = true;
                 } else {
-                    cur = atomicCAS((unsigned long long*)&L.nkeys[h], KMC_EMPTY64, nk);
-                    if (cur == KMC_EMPTY64) { atomicAdd(&L.nnodes, 1u); cur = nk; }
+                    advance = true;
                 }
             }
-            if (!done) {
-                if (cur == nk) { res = h; done = true; }
-                else {
-                    h = (h + 1) & (KMC_WALK_NCAP - 1);
-                    if (h == 0) h = 1;
-                    if (++probes > 64) done = true;
-                }
+            if (advance) {
+                h = (h + 1) & (KMC_WALK_NCAP - 1);
+                if (h == 0) h = 1;
+                if (++probes > 64) done = true;
             }
         }
     }
@@ -148,23 +212,23 @@ __device__ __forceinline__ u32 walk_node(WalkLds& L, u64 nk) {
 }
 
 // Slow path of one step from node offset `s` (s == 0: direct mode).  Returns the next state.
-template <bool CANON>
-__device__ __forceinline__ u32 walk_slow(WalkLds& L, const GTable& g, u32 s, u32 label, int len, int k, u64 mask,
-                                         u64& dctx, u32& ddepth, u64& ndirect) {
+template <int KW, bool CANON>
+__device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s, u32 label, int len, int k,
+                                         u64 mask_hi, u64 mask_lo, WCtx& dctx, u32& ddepth, u64& ndirect) {
     if (s == 0) {  // direct mode: roll the context and count every k-mer with a global atomic
-        ndirect += walk_roll<CANON, true>(g, dctx, ddepth, label, len, k, mask, 1);
+        ndirect += walk_roll<KW, CANON, true>(g, dctx, ddepth, label, len, k, mask_hi, mask_lo, 1);
         return 0;
     }
     const u32 id = s >> 4;
     // successor context (needed to create an edge) -- built once, lazily
     bool have_succ = false;
     u32 sid = 0;  // successor node id, 0 = none / table full
-    u64 sctx = 0;
+    WCtx sctx = {0, 0};
     u32 sdepth = 0;
     auto make_succ = [&]() {
-        node_decode(__hip_atomic_load(&L.nkeys[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), k, sctx, sdepth);
-        (void)walk_roll<CANON, false>(g, sctx, sdepth, label, len, k, mask, 0);
-        sid = (len == KMC_WALK_STRIDE) ? walk_node(L, node_encode(sctx, sdepth, k, mask)) : 0;
+        node_decode<KW>(node_key_load<KW>(L, id), k, sctx, sdepth);
+        (void)walk_roll<KW, CANON, false>(g, sctx, sdepth, label, len, k, mask_hi, mask_lo, 0);
+        sid = (len == KMC_WALK_STRIDE) ? walk_node<KW>(L, node_encode<KW>(sctx, sdepth, k, mask_hi, mask_lo)) : 0;
         have_succ = true;
     };
     WalkNode* np = reinterpret_cast<WalkNode*>(reinterpret_cast<char*>(L.node) + s);
@@ -224,10 +288,10 @@ __device__ __forceinline__ u32 walk_slow(WalkLds& L, const GTable& g, u32 s, u32
     }
     if (found) return val << 4;  // (a <16-base step ends the read; its successor is unused)
     // 3. memo full: count this step's k-mers directly from the node's context
-    u64 ctx;
+    WCtx ctx;
     u32 depth;
-    node_decode(__hip_atomic_load(&L.nkeys[id], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), k, ctx, depth);
-    ndirect += walk_roll<CANON, true>(g, ctx, depth, label, len, k, mask, 1);
+    node_decode<KW>(node_key_load<KW>(L, id), k, ctx, depth);
+    ndirect += walk_roll<KW, CANON, true>(g, ctx, depth, label, len, k, mask_hi, mask_lo, 1);
     if (len != KMC_WALK_STRIDE) return 0;
     if (!have_succ) make_succ();
     if (sid) return sid << 4;  // successor node exists: stay on the memoised path
@@ -255,26 +319,29 @@ __device__ __forceinline__ u32 walk_encode16(uint4 v, u32& x0, u32& x1, u32& x2,
     return u;
 }
 
-template <bool CANON>
+template <int KW, bool CANON>
 __global__ __launch_bounds__(KMC_WALK_THREADS)
 void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets, u64 n_reads,
                      int k, WalkWs* ws, u32* deferred, GTable g) {
     extern __shared__ __align__(16) unsigned char walk_smem[];
-    WalkLds& L = *reinterpret_cast<WalkLds*>(walk_smem);
+    WalkLds<KW>& L = *reinterpret_cast<WalkLds<KW>*>(walk_smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const u64 mask = (1ull << (2 * k)) - 1;
+    const int kb = 2 * k;
+    const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
+    const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
 
     for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) { L.edge[i].kv = ~0ull; L.edge[i].cnt = 0; }
     for (int i = tid; i < KMC_WALK_NCAP; i += KMC_WALK_THREADS) {
-        L.nkeys[i] = KMC_EMPTY64;
+        L.nkeys[i] = KW == 1 ? KMC_EMPTY64 : 0ull;
+        if (KW == 2) L.nkeys_hi[i] = KMC_EMPTY64;
         L.node[i].prim = 0; L.node[i].cnt = 0;
     }
     if (tid == 0) { L.nedges = 0; L.nnodes = 1; }
     __syncthreads();
-    const u64 root_key = KMC_NODE_PREFIX;  // prefix node of depth 0
-    u32 root_id = (u32)(kmc_mix64(root_key) >> (64 - KMC_WALK_NLOG));
+    const WCtx root_key = node_encode<KW>(WCtx{0, 0}, 0, k, mask_hi, mask_lo);  // prefix node of depth 0
+    u32 root_id = (u32)(kmc_hash_key<KW>(root_key.hi, root_key.lo) >> (64 - KMC_WALK_NLOG));
     if (root_id == 0) root_id = 1;
-    if (tid == 0) L.nkeys[root_id] = root_key;
+    if (tid == 0) { L.nkeys[root_id] = root_key.lo; if (KW == 2) L.nkeys_hi[root_id] = root_key.hi; }
     __syncthreads();
     const u32 s_root = root_id << 4;
 
@@ -394,7 +461,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         const u32 tail = mine ? (len_read & 15) : 0;
         const u32 nsteps = nfull + (tail ? 1u : 0u);
         u32 s = s_root;
-        u64 dctx = 0;
+        WCtx dctx = {0, 0};
         u32 ddepth = 0;
         u32 wc = mine ? stage[w0] : 0;
         for (u32 t = 0; t < KMC_WALK_MAX_READ / KMC_WALK_STRIDE + 1; ++t) {
@@ -413,7 +480,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
                     s = (u32)(pe >> 32);
                 } else {
                     if (!full) label &= (1u << (2 * tail)) - 1u;
-                    s = walk_slow<CANON>(L, g, s, label, full ? KMC_WALK_STRIDE : (int)tail, k, mask, dctx, ddepth, ndirect);
+                    s = walk_slow<KW, CANON>(L, g, s, label, full ? KMC_WALK_STRIDE : (int)tail, k, mask_hi, mask_lo, dctx, ddepth, ndirect);
                 }
             }
         }
@@ -440,10 +507,10 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
             label = (u32)kv; len = ((u32)(kv >> 32) & 15u) + 1; id = (u32)(kv >> 36) & (KMC_WALK_NCAP - 1);
         }
         if (cnt) {
-            u64 ctx;
+            WCtx ctx;
             u32 depth;
-            node_decode(L.nkeys[id], k, ctx, depth);
-            (void)walk_roll<CANON, true>(g, ctx, depth, label, (int)len, k, mask, cnt);
+            node_decode<KW>(node_key_load<KW>(L, id), k, ctx, depth);
+            (void)walk_roll<KW, CANON, true>(g, ctx, depth, label, (int)len, k, mask_hi, mask_lo, cnt);
         }
     }
 }
@@ -489,9 +556,19 @@ static inline bool kmc_walk_supported(int k, int mode, u64 max_read_len) {
 }
 static inline size_t kmc_walk_workspace_bytes(u64 n_reads) { return sizeof(WalkWs) + (size_t)(n_reads + 16) * sizeof(u32); }
 
+template <int KW, bool CANON>
+static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const uint8_t* d_bases, const u64* d_offsets,
+                                     u64 n_reads, u64 n_bases, int k, WalkWs* hdr, u32* list, GTable g) {
+    const size_t smem = sizeof(WalkLds<KW>);
+    static bool attr = false;  // one flag per instantiation
+    if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<KW, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+    hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, hdr, list, g);
+    hipLaunchKernelGGL((kmc_scalar_reads_kernel<KW, CANON>), dim3(n_cu), dim3(256), 0, st, d_bases, d_offsets, hdr, list, k, g);
+}
+
 static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool canon, const uint8_t* d_bases,
                                   const u64* d_offsets, u64 n_reads, u64 n_bases, void* ws, GTable g) {
-    if (KW != 1 || n_reads >= (1ull << 32)) return KMC_ERR_ARG;
+    if (n_reads >= (1ull << 32)) return KMC_ERR_ARG;
     WalkWs* hdr = (WalkWs*)ws;
     u32* list = (u32*)((char*)ws + sizeof(WalkWs));
     if (hipMemsetAsync(hdr, 0, sizeof(WalkWs), st) != hipSuccess) return KMC_ERR_HIP;
@@ -499,18 +576,12 @@ static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool 
     u64 want = (n_tiles + KMC_WALK_WAVES - 1) / KMC_WALK_WAVES;
     int grid = (int)(want < (u64)n_cu ? want : (u64)n_cu);  // one 160 KB workgroup per CU is resident
     if (grid < 1) grid = 1;
-    const size_t smem = sizeof(WalkLds);
-    if (canon) {
-        static bool attr1 = false;
-        if (!attr1) { (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr1 = true; }
-        hipLaunchKernelGGL(kmc_walk_kernel<true>, dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, hdr, list, g);
-        hipLaunchKernelGGL((kmc_scalar_reads_kernel<1, true>), dim3(n_cu), dim3(256), 0, st, d_bases, d_offsets, hdr, list, k, g);
+    if (KW == 1) {
+        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, g);
+        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, g);
     } else {
-        static bool attr0 = false;
-        if (!attr0) { (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr0 = true; }
-        hipLaunchKernelGGL(kmc_walk_kernel<false>, dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, hdr, list, g);
-        hipLaunchKernelGGL((kmc_scalar_reads_kernel<1, false>), dim3(n_cu), dim3(256), 0, st, d_bases, d_offsets, hdr, list, k, g);
+        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, g);
+        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, g);
     }
     return hipGetLastError() == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
-

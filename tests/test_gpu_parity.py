@@ -15,9 +15,9 @@ LR = json.load(open(os.path.join(GOLDEN, "lr_goldens.json")))["cases"]
 
 
 def _algos(kmc, k, max_read_len=None):
-    """Every algorithm that can take this input (WALK: k <= 31 and reads <= 416 bases)."""
+    """Every algorithm that can take this input (WALK: reads <= 416 bases)."""
     a = [kmc.ALGO_STREAM, kmc.ALGO_AUTO]
-    if k <= 31 and (max_read_len is None or 1 <= max_read_len <= 416):
+    if k <= 63 and (max_read_len is None or 1 <= max_read_len <= 416):
         a.append(kmc.ALGO_WALK)
     return a
 
@@ -91,7 +91,7 @@ def test_walk_short_reads(kmc, oracle, seed):
     scalar kernel), pool-like low cardinality and full-random high cardinality (memo overflow ->
     direct counting), every step-tail length."""
     rng = np.random.default_rng(200 + seed)
-    for k in (3, 8, 9, 21, 31):
+    for k in (3, 8, 9, 21, 31, 32, 40, 63):
         hi = int(rng.choice([20, 100, 250, 416]))
         bases, offs = _random_reads(rng, int(rng.integers(1, 6000)), 0, hi, p_bad=float(rng.choice([0, 0.002])))
         if seed % 2 == 0:
@@ -342,7 +342,7 @@ def test_walk_repeatability_stress(kmc, oracle):
     buffers get reused) -- guards against races in the LDS memo and against stale reads."""
     rng = np.random.default_rng(7)
     for it in range(40):
-        k = int(rng.choice([17, 24, 31]))
+        k = int(rng.choice([17, 24, 31, 47]))
         lens = rng.integers(0, 301, 300) if it % 2 else np.full(300, 150)
         offs = np.zeros(301, np.uint64)
         offs[1:] = np.cumsum(lens)
