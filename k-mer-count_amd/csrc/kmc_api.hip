@@ -64,6 +64,7 @@ struct kmc_ctx {
     bool sorted_valid = false;
     // walk-kernel workspace
     DevBuf walk_ws;
+    DevBuf walk_memo;  // per-workgroup memo slots, kept across launches (kmc_walk.cuh)
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the whole batch
     std::vector<hipEvent_t> lev;              // pairs bracketing every count-kernel launch of the batch
@@ -349,10 +350,17 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
         size_t ws_bytes = kmc_walk_workspace_bytes(n_reads);
         rc = ensure(c, c->walk_ws, ws_bytes);
         if (rc) return rc;
+        if (!c->walk_memo.p || c->walk_overflowed) {
+            // (re)start from an empty memo: first use, or the last batch overflowed it (its entries
+            // were not representative; keeping them would only hold the tables full)
+            rc = ensure(c, c->walk_memo, kmc_walk_memo_bytes(c->n_cu, c->KW));
+            if (rc) return rc;
+            HIPCHK(c, hipMemsetAsync(c->walk_memo.p, 0, kmc_walk_memo_bytes(c->n_cu, c->KW), c->stream));
+        }
         rc = launch_begin(c);
         if (rc) return rc;
         rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_offsets, n_reads, n_bases,
-                             c->walk_ws.p, gtable_of(c, c->tab));
+                             c->walk_ws.p, c->walk_memo.p, gtable_of(c, c->tab));
         if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
         rc = launch_end(c);
         if (rc) return rc;
@@ -441,7 +449,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     if (c->spill_lo) (void)hipFree(c->spill_lo);
     if (c->spill_cnt) (void)hipFree(c->spill_cnt);
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
-                      &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws};
+                      &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo};
     for (DevBuf* b : bufs) free_buf(*b);
     for (hipEvent_t e : c->lev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -589,14 +597,18 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
     for (DevBuf* b : need) { rc = ensure(c, *b, nb); if (rc) return rc; }
     if (c->KW == 2) { rc = ensure(c, c->o_hi, nb); if (rc) return rc; rc = ensure(c, c->t_hi, nb); if (rc) return rc; }
     if (n) {
-        HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_OUT], 0, sizeof(u64), c->stream));
+        static_assert(KMC_CTR_SUM == KMC_CTR_OUT + 2 && KMC_CTR_BADBASE == KMC_CTR_OUT + 1, "OUT..SUM are cleared together");
+        {   // clear OUT and SUM (BADBASE, between them, must survive: save/restore is not needed -- it is
+            // only read by poll() deltas, so clear the two words separately)
+            HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_OUT], 0, sizeof(u64), c->stream));
+            HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM], 0, sizeof(u64), c->stream));
+        }
         GTable g = gtable_of(c, c->tab);
         int grid = grid_for(c, c->tab.cap, 256);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_compact_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->t_lo.p, (u64*)c->t_cnt.p);
-        else hipLaunchKernelGGL(kmc_compact_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)c->t_hi.p, (u64*)c->t_lo.p, (u64*)c->t_cnt.p);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_compact_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p);
+        else hipLaunchKernelGGL(kmc_compact_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)c->t_hi.p, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p);
         HIPCHK(c, hipGetLastError());
         int g2 = grid_for(c, n, 256);
-        hipLaunchKernelGGL(kmc_iota_kernel, dim3(g2), dim3(256), 0, c->stream, (u64*)c->t_idx0.p, n);
         const unsigned kb = 2u * (unsigned)c->klen;
         if (c->KW == 1) {
             rc = sort_pairs<u64>(c, (const u64*)c->t_lo.p, (u64*)c->o_lo.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, std::max(kb, 1u));
@@ -612,8 +624,6 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
             hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_lo.p, (const u64*)c->t_idx0.p, (u64*)c->o_lo.p, n);
             hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_cnt.p, (const u64*)c->t_idx0.p, (u64*)c->o_cnt.p, n);
         }
-        HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM], 0, sizeof(u64), c->stream));
-        hipLaunchKernelGGL(kmc_sum_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->o_cnt.p, n, c->d_counters);
         HIPCHK(c, hipGetLastError());
         rc = poll(c);
         if (rc) return rc;

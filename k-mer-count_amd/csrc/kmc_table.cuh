@@ -5,18 +5,26 @@
 #pragma once
 #include "kmc_device.cuh"
 
+// occupied slots -> dense (hi, lo, cnt) arrays, plus the identity permutation for the sort and the
+// sum of all counts (counters[KMC_CTR_SUM]) in the same pass
 template <int KW>
-__global__ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_cnt) {
+__global__ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_cnt, u64* out_idx) {
     const u64 cap = g.capmask + 1;
+    u64 sum = 0;
     for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (u64)gridDim.x * blockDim.x) {
         bool occ = (KW == 1) ? (g.key_lo[s] != KMC_EMPTY64) : (g.key_hi[s] != KMC_EMPTY64);
         if (occ) {
             u64 idx = atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OUT], 1ull);
             if (KW == 2) out_hi[idx] = g.key_hi[s];
             out_lo[idx] = g.key_lo[s];
-            out_cnt[idx] = g.count[s];
+            const u64 c = g.count[s];
+            out_cnt[idx] = c;
+            out_idx[idx] = idx;
+            sum += c;
         }
     }
+    sum = wave_sum_u64(sum);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_SUM], sum);
 }
 
 // re-insert every entry of `old` into `g` (growth)

@@ -77,6 +77,20 @@ struct WalkWs {
     unsigned long long pad[7];
 };
 
+// The memo (nodes, node keys, edges -- no counters) is input-independent graph structure, so it is
+// kept across launches: every workgroup saves its tables to its slot at the end of a launch and
+// starts the next launch from them, which removes the per-launch warm-up of the slow path.
+template <int KW>
+struct WalkMemoSlot {
+    u64 tag;  // KMC_WALK_MEMO_TAG | k when valid
+    u32 nedges, nnodes;
+    u64 prim[KMC_WALK_NCAP];
+    u64 nkeys[KMC_WALK_NCAP];
+    u64 nkeys_hi[KW == 2 ? KMC_WALK_NCAP : 1];
+    u64 ekv[KMC_WALK_ECAP];
+};
+#define KMC_WALK_MEMO_TAG 0x4B4D434D454D4F00ull
+
 // A context: up to 63 bases, 2 bits each in the public coding A0 C1 G2 T3, newest base in the low
 // bits of lo.  hi stays 0 when KW == 1 (k <= 31).
 struct WCtx { u64 hi, lo; };
@@ -322,7 +336,7 @@ __device__ __forceinline__ u32 walk_encode16(uint4 v, u32& x0, u32& x1, u32& x2,
 template <int KW, bool CANON>
 __global__ __launch_bounds__(KMC_WALK_THREADS)
 void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets, u64 n_reads,
-                     int k, WalkWs* ws, u32* deferred, GTable g) {
+                     int k, WalkWs* ws, u32* deferred, WalkMemoSlot<KW>* memo_slots, GTable g) {
     extern __shared__ __align__(16) unsigned char walk_smem[];
     WalkLds<KW>& L = *reinterpret_cast<WalkLds<KW>*>(walk_smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -330,18 +344,21 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
 
-    for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) { L.edge[i].kv = ~0ull; L.edge[i].cnt = 0; }
+    WalkMemoSlot<KW>* memo = memo_slots ? &memo_slots[blockIdx.x] : nullptr;
+    const bool warm = memo && memo->tag == (KMC_WALK_MEMO_TAG | (u64)k);  // workgroup-uniform
+    for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) { L.edge[i].kv = warm ? memo->ekv[i] : ~0ull; L.edge[i].cnt = 0; }
     for (int i = tid; i < KMC_WALK_NCAP; i += KMC_WALK_THREADS) {
-        L.nkeys[i] = KW == 1 ? KMC_EMPTY64 : 0ull;
-        if (KW == 2) L.nkeys_hi[i] = KMC_EMPTY64;
-        L.node[i].prim = 0; L.node[i].cnt = 0;
+        L.nkeys[i] = warm ? memo->nkeys[i] : (KW == 1 ? KMC_EMPTY64 : 0ull);
+        if (KW == 2) L.nkeys_hi[i] = warm ? memo->nkeys_hi[i] : KMC_EMPTY64;
+        L.node[i].prim = warm ? memo->prim[i] : 0ull;
+        L.node[i].cnt = 0;
     }
-    if (tid == 0) { L.nedges = 0; L.nnodes = 1; }
+    if (tid == 0) { L.nedges = warm ? memo->nedges : 0; L.nnodes = warm ? memo->nnodes : 1; }
     __syncthreads();
     const WCtx root_key = node_encode<KW>(WCtx{0, 0}, 0, k, mask_hi, mask_lo);  // prefix node of depth 0
     u32 root_id = (u32)(kmc_hash_key<KW>(root_key.hi, root_key.lo) >> (64 - KMC_WALK_NLOG));
     if (root_id == 0) root_id = 1;
-    if (tid == 0) { L.nkeys[root_id] = root_key.lo; if (KW == 2) L.nkeys_hi[root_id] = root_key.hi; }
+    if (tid == 0 && !warm) { L.nkeys[root_id] = root_key.lo; if (KW == 2) L.nkeys_hi[root_id] = root_key.hi; }
     __syncthreads();
     const u32 s_root = root_id << 4;
 
@@ -513,6 +530,16 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
             (void)walk_roll<KW, CANON, true>(g, ctx, depth, label, (int)len, k, mask_hi, mask_lo, cnt);
         }
     }
+    // ---- save the memo (structure only) for the next launch ----
+    if (memo) {
+        for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) memo->ekv[i] = L.edge[i].kv;
+        for (int i = tid; i < KMC_WALK_NCAP; i += KMC_WALK_THREADS) {
+            memo->nkeys[i] = L.nkeys[i];
+            if (KW == 2) memo->nkeys_hi[i] = L.nkeys_hi[i];
+            memo->prim[i] = L.node[i].prim;
+        }
+        if (tid == 0) { memo->nedges = L.nedges; memo->nnodes = L.nnodes; memo->tag = KMC_WALK_MEMO_TAG | (u64)k; }
+    }
 }
 
 // One lane per listed read, byte by byte: reads diverted from the walk kernel (non-ACGT bytes).
@@ -554,20 +581,21 @@ __global__ void kmc_scalar_reads_kernel(const uint8_t* __restrict__ bases, const
 static inline bool kmc_walk_supported(int k, int mode, u64 max_read_len) {
     return mode == KMC_MODE_CONTIG && k >= 1 && k <= KMC_WALK_MAX_K && max_read_len >= 1 && max_read_len <= KMC_WALK_MAX_READ;
 }
+static inline size_t kmc_walk_memo_bytes(int n_cu, int KW) { return (size_t)n_cu * (KW == 1 ? sizeof(WalkMemoSlot<1>) : sizeof(WalkMemoSlot<2>)); }
 static inline size_t kmc_walk_workspace_bytes(u64 n_reads) { return sizeof(WalkWs) + (size_t)(n_reads + 16) * sizeof(u32); }
 
 template <int KW, bool CANON>
 static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const uint8_t* d_bases, const u64* d_offsets,
-                                     u64 n_reads, u64 n_bases, int k, WalkWs* hdr, u32* list, GTable g) {
+                                     u64 n_reads, u64 n_bases, int k, WalkWs* hdr, u32* list, void* memo, GTable g) {
     const size_t smem = sizeof(WalkLds<KW>);
     static bool attr = false;  // one flag per instantiation
     if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<KW, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-    hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, hdr, list, g);
+    hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, hdr, list, (WalkMemoSlot<KW>*)memo, g);
     hipLaunchKernelGGL((kmc_scalar_reads_kernel<KW, CANON>), dim3(n_cu), dim3(256), 0, st, d_bases, d_offsets, hdr, list, k, g);
 }
 
 static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool canon, const uint8_t* d_bases,
-                                  const u64* d_offsets, u64 n_reads, u64 n_bases, void* ws, GTable g) {
+                                  const u64* d_offsets, u64 n_reads, u64 n_bases, void* ws, void* memo, GTable g) {
     if (n_reads >= (1ull << 32)) return KMC_ERR_ARG;
     WalkWs* hdr = (WalkWs*)ws;
     u32* list = (u32*)((char*)ws + sizeof(WalkWs));
@@ -577,11 +605,11 @@ static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool 
     int grid = (int)(want < (u64)n_cu ? want : (u64)n_cu);  // one 160 KB workgroup per CU is resident
     if (grid < 1) grid = 1;
     if (KW == 1) {
-        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, g);
-        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, g);
+        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, memo, g);
+        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, memo, g);
     } else {
-        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, g);
-        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, g);
+        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, memo, g);
+        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, memo, g);
     }
     return hipGetLastError() == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
