@@ -12,8 +12,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <vector>
 
 #include "../../include/kmc.h"
@@ -29,89 +32,147 @@ void set_err(char* errbuf, size_t n, const char* msg) {
 
 }  // namespace
 
+// Multi-threaded reader.  The file is cut into byte segments; every worker snaps its segment to
+// line starts, then makes one memchr pass over it: a line starting with '>' opens a record, any
+// other line is trimmed on the right and appended to the worker's local sequence buffer.  The
+// workers' results are stitched in order (sequence bytes before a worker's first header belong to
+// the last record of an earlier worker), which gives exactly the sequential reader's result.
+namespace {
+
+struct SegOut {
+    std::vector<uint8_t> seq;        // sequence bytes of this segment, in order
+    std::vector<uint64_t> rec_start; // local offset in `seq` where each record of this segment starts
+    std::vector<uint8_t> rec_blank;  // header was empty (id "", no desc)
+    bool bad_first_line = false;     // segment 0 only: a non-header line before any header
+    int err = 0;
+};
+
+void parse_segment(const char* path, uint64_t begin, uint64_t end, uint64_t fsize, bool first, SegOut* out) {
+    FILE* f = fopen(path, "rb");
+    if (!f) { out->err = KMC_ERR_IO; return; }
+    // snap `begin` to the first line start >= begin (unless it is the file start)
+    const size_t BUF = 1u << 22;
+    std::vector<char> buf(BUF);
+    uint64_t pos = begin;
+    if (begin > 0) {
+        // the line containing byte begin-1 belongs to the previous segment: skip to after its '\n'
+        fseeko(f, (off_t)(begin - 1), SEEK_SET);
+        pos = begin - 1;
+        bool found = false;
+        while (!found && pos < fsize) {
+            size_t got = fread(buf.data(), 1, BUF, f);
+            if (!got) break;
+            const char* nl = (const char*)memchr(buf.data(), '\n', got);
+            if (nl) { pos += (uint64_t)(nl - buf.data()) + 1; found = true; } else pos += got;
+        }
+        if (!found) { fclose(f); return; }  // no line starts in this segment
+    }
+    if (pos >= end && !(first && fsize == 0)) { if (pos >= end) { fclose(f); return; } }
+    fseeko(f, (off_t)pos, SEEK_SET);
+    out->seq.reserve((size_t)(end > pos ? end - pos : 0) + 64);
+    std::string carry;  // a line cut by the read buffer
+    bool in_record = false;
+    bool stop = false;
+    auto handle_line = [&](const char* s, size_t n, uint64_t line_start) {
+        if (line_start >= end) { stop = true; return; }  // first line of the next segment
+        if (n && s[0] == '>') {
+            size_t e = n;
+            while (e > 1 && is_space((unsigned char)s[e - 1])) e--;
+            out->rec_start.push_back(out->seq.size());
+            out->rec_blank.push_back(e <= 1);
+            in_record = true;
+            return;
+        }
+        if (first && !in_record) { out->bad_first_line = true; stop = true; return; }
+        size_t e = n;
+        while (e > 0 && is_space((unsigned char)s[e - 1])) e--;
+        out->seq.insert(out->seq.end(), (const uint8_t*)s, (const uint8_t*)s + e);
+    };
+    uint64_t line_start = pos;
+    while (!stop) {
+        size_t got = fread(buf.data(), 1, BUF, f);
+        if (!got) break;
+        size_t p = 0;
+        while (p < got && !stop) {
+            const char* nl = (const char*)memchr(buf.data() + p, '\n', got - p);
+            size_t e = nl ? (size_t)(nl - buf.data()) : got;
+            if (!carry.empty() || !nl) {
+                carry.append(buf.data() + p, e - p);
+                if (nl) { handle_line(carry.data(), carry.size(), line_start); line_start += carry.size() + 1; carry.clear(); }
+            } else {
+                handle_line(buf.data() + p, e - p, line_start);
+                line_start += (e - p) + 1;
+            }
+            p = nl ? e + 1 : got;
+        }
+    }
+    if (!stop && !carry.empty()) handle_line(carry.data(), carry.size(), line_start);  // last line without '\n'
+    fclose(f);
+}
+
+}  // namespace
+
 extern "C" int kmc_parse_fasta(const char* path, kmc_reads* out, char* errbuf, size_t errbuf_len) {
     if (!out || !path) return KMC_ERR_ARG;
     memset(out, 0, sizeof(*out));
     FILE* f = fopen(path, "rb");
     if (!f) { set_err(errbuf, errbuf_len, "Error during opening the file"); return KMC_ERR_IO; }
-    std::vector<uint8_t> seq;
-    std::vector<uint64_t> offs;
-    offs.push_back(0);
+    fseeko(f, 0, SEEK_END);
+    const uint64_t fsize = (uint64_t)ftello(f);
+    fclose(f);
     try {
-        // streaming line reader: the file is never held whole
-        const size_t BUFSZ = 1u << 22;
-        std::vector<char> buf(BUFSZ);
-        std::string line;       // current (possibly partial) line
-        bool in_record = false; // a header has been seen
-        bool header_blank = false;
-        uint64_t rec_start = 0;
-        uint64_t maxlen = 0;
-        bool stop = false;
-        auto finish_record = [&]() {
-            // Record::is_empty(): id "", no desc, no sequence -> treated as EOF by main.rs:60-62
-            if (header_blank && seq.size() == rec_start) { stop = true; return; }
-            offs.push_back(seq.size());
-            uint64_t l = seq.size() - rec_start;
-            if (l > maxlen) maxlen = l;
-        };
-        auto handle_line = [&](const char* s, size_t n) -> int {
-            if (n && s[0] == '>') {
-                if (in_record) finish_record();
-                if (stop) return 0;
-                size_t e = n;
-                while (e > 1 && is_space((unsigned char)s[e - 1])) e--;
-                header_blank = (e <= 1);
-                in_record = true;
-                rec_start = seq.size();
-                return 0;
-            }
-            if (!in_record) return KMC_ERR_FORMAT;  // includes a blank first line, like bio
-            size_t e = n;
-            while (e > 0 && is_space((unsigned char)s[e - 1])) e--;
-            seq.insert(seq.end(), (const uint8_t*)s, (const uint8_t*)s + e);
-            return 0;
-        };
-        int rc = 0;
-        size_t got;
-        while (!stop && (got = fread(buf.data(), 1, BUFSZ, f)) > 0) {
-            size_t pos = 0;
-            while (pos < got && !stop) {
-                const char* nl = (const char*)memchr(buf.data() + pos, '\n', got - pos);
-                size_t end = nl ? (size_t)(nl - buf.data()) : got;
-                if (!line.empty() || !nl) {
-                    line.append(buf.data() + pos, end - pos);
-                    if (nl) { rc = handle_line(line.data(), line.size()); line.clear(); }
-                } else {
-                    rc = handle_line(buf.data() + pos, end - pos);
-                }
-                if (rc) break;
-                pos = nl ? end + 1 : got;
-            }
-            if (rc) break;
+        unsigned hw = std::thread::hardware_concurrency();
+        uint64_t nseg = std::min<uint64_t>(std::max(1u, std::min(hw, 32u)), std::max<uint64_t>(1, fsize >> 24));  // >= 16 MiB each
+        std::vector<SegOut> segs((size_t)nseg);
+        std::vector<std::thread> th;
+        for (uint64_t i = 0; i < nseg; ++i) {
+            uint64_t b = fsize * i / nseg, e = fsize * (i + 1) / nseg;
+            th.emplace_back(parse_segment, path, b, e, fsize, i == 0, &segs[(size_t)i]);
         }
-        if (!rc && !stop && !line.empty()) rc = handle_line(line.data(), line.size());
-        fclose(f);
-        f = nullptr;
-        if (rc) { set_err(errbuf, errbuf_len, "Expected > at record start."); return rc; }
-        if (in_record && !stop) finish_record();
-        out->n_reads = offs.size() - 1;
-        out->n_bases = seq.size();
-        out->max_read_len = maxlen;
-        out->bases = (uint8_t*)malloc(seq.size() + 64);
-        out->offsets = (uint64_t*)malloc(offs.size() * sizeof(uint64_t));
+        for (auto& t : th) t.join();
+        for (auto& sg : segs) if (sg.err) { set_err(errbuf, errbuf_len, "Error during opening the file"); return sg.err; }
+        if (segs[0].bad_first_line) { set_err(errbuf, errbuf_len, "Expected > at record start."); return KMC_ERR_FORMAT; }
+        // stitch
+        uint64_t total = 0, nrec = 0;
+        for (auto& sg : segs) { total += sg.seq.size(); nrec += sg.rec_start.size(); }
+        out->bases = (uint8_t*)malloc((size_t)total + 64);
+        out->offsets = (uint64_t*)malloc((size_t)(nrec + 1) * sizeof(uint64_t));
         if (!out->bases || !out->offsets) {
             free(out->bases); free(out->offsets);
             memset(out, 0, sizeof(*out));
             set_err(errbuf, errbuf_len, "out of memory");
             return KMC_ERR_NOMEM;
         }
-        if (!seq.empty()) memcpy(out->bases, seq.data(), seq.size());
-        memcpy(out->offsets, offs.data(), offs.size() * sizeof(uint64_t));
+        std::vector<uint8_t> blank((size_t)nrec);
+        uint64_t base = 0, r = 0;
+        std::vector<std::thread> cp;
+        for (auto& sg : segs) {
+            for (size_t j = 0; j < sg.rec_start.size(); ++j) { out->offsets[r] = base + sg.rec_start[j]; blank[(size_t)r] = sg.rec_blank[j]; r++; }
+            if (!sg.seq.empty()) cp.emplace_back([dst = out->bases + base, &sg]() { memcpy(dst, sg.seq.data(), sg.seq.size()); });
+            base += sg.seq.size();
+        }
+        for (auto& t : cp) t.join();
+        out->offsets[nrec] = total;
+        // Record::is_empty(): a record with empty header and no sequence ends the input (main.rs:60-62)
+        uint64_t keep = nrec;
+        for (uint64_t i = 0; i < nrec; ++i)
+            if (blank[(size_t)i] && out->offsets[i + 1] == out->offsets[i]) { keep = i; break; }
+        if (keep < nrec) { total = out->offsets[keep]; nrec = keep; }
+        uint64_t maxlen = 0;
+        for (uint64_t i = 0; i < nrec; ++i) maxlen = std::max<uint64_t>(maxlen, out->offsets[i + 1] - out->offsets[i]);
+        out->n_reads = nrec;
+        out->n_bases = total;
+        out->max_read_len = maxlen;
         return KMC_OK;
     } catch (const std::bad_alloc&) {
-        if (f) fclose(f);
+        free(out->bases); free(out->offsets);
         memset(out, 0, sizeof(*out));
         set_err(errbuf, errbuf_len, "out of memory");
+        return KMC_ERR_NOMEM;
+    } catch (const std::system_error&) {
+        free(out->bases); free(out->offsets);
+        memset(out, 0, sizeof(*out));
+        set_err(errbuf, errbuf_len, "cannot start parser threads");
         return KMC_ERR_NOMEM;
     }
 }

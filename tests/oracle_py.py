@@ -80,8 +80,10 @@ def parse_fasta(path):
         raise OracleError(rc, L.kmo_strerror(rc).decode())
     try:
         nb, nr = int(rd.n_bases), int(rd.n_reads)
-        bases = np.ctypeslib.as_array(rd.bases, shape=(nb,)).copy() if nb else np.zeros(0, np.uint8)
-        offsets = np.ctypeslib.as_array(rd.offsets, shape=(nr + 1,)).copy()
+        # (np.ctypeslib.as_array on a POINTER is very slow for GB-sized buffers)
+        bases = (np.frombuffer((C.c_uint8 * nb).from_address(C.addressof(rd.bases.contents)), dtype=np.uint8).copy()
+                 if nb else np.zeros(0, np.uint8))
+        offsets = np.frombuffer((C.c_uint64 * (nr + 1)).from_address(C.addressof(rd.offsets.contents)), dtype=np.uint64).copy()
     finally:
         L.kmo_free_reads(C.byref(rd))
     return bases, offsets

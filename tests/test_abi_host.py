@@ -141,3 +141,24 @@ def test_table_formatting(kmc):
     assert t.to_bytes() == b"AC\t2\nTG\t1\n"
     assert t.to_bytes(expand=True) == b"AC\nAC\nTG\n"
     assert t.n_total == 3
+
+
+def test_host_fasta_reader_multi_segment(kmc, oracle, tmp_path):
+    """Files above 32 MiB are parsed by several threads (16 MiB segments snapped to line starts):
+    same result as the sequential oracle reader, including records and long lines that straddle
+    segment boundaries, CRLF endings and a missing final newline."""
+    exe = os.path.join(ROOT, "bin", "kmc-genfasta")
+    p = tmp_path / "big.fasta"
+    with open(p, "wb") as f:
+        subprocess.run([exe, "--bytes", "60000000", "--seed", "11"], stdout=f, check=True)
+    b1, o1 = kmc.parse_fasta(str(p))
+    b2, o2 = oracle.parse_fasta(str(p))
+    assert o1.shape[0] > 100_000 and np.array_equal(o1, o2) and np.array_equal(b1, b2)
+    # one 20 MB line inside a 50 MB file + CRLF + no trailing newline
+    rng = np.random.default_rng(3)
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 50_000_000)].tobytes()
+    q = tmp_path / "long.fasta"
+    q.write_bytes(b">a\r\n" + seq[:20_000_000] + b"\r\n" + seq[20_000_000:35_000_000] + b"\n>b x\n" + seq[35_000_000:] )
+    b1, o1 = kmc.parse_fasta(str(q))
+    b2, o2 = oracle.parse_fasta(str(q))
+    assert o1.tolist() == [0, 35_000_000, 50_000_000] and np.array_equal(o1, o2) and np.array_equal(b1, b2)
