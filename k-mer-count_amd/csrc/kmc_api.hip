@@ -75,6 +75,8 @@ struct kmc_ctx {
     u64 direct_seen = 0, kmers_seen = 0;
     bool pending = false;  // a batch has been queued since the last counter poll
     double rho_last = 0.0; // same, over the most recent sub-batch
+    double rho_hist = -1.0; // largest sub-batch ratio of the previous batch (< 0: no history); survives kmc_reset
+    bool b_open = false; double b_rho_max = 0.0; u64 b_occ0 = 0, b_kmers = 0;  // the batch whose last launch is still unobserved
     double rho_max = 0.0;  // largest observed (new distinct) / (k-mers) over a sub-batch
     int n_cu = 256;
 };
@@ -181,6 +183,13 @@ int poll(kmc_ctx* c) {
         c->direct_seen = d;
         c->kmers_seen = n;
     }
+    if (c->b_open) {
+        // history for the next batch's launch plan: new keys per k-mer of the batch just finished
+        u64 occ = c->h_counters[KMC_CTR_OCCUPIED] + c->h_counters[KMC_CTR_SPILL];
+        double whole = (double)(occ > c->b_occ0 ? occ - c->b_occ0 : 0) / (double)c->b_kmers;
+        c->rho_hist = std::max(c->b_rho_max, whole);
+        c->b_open = false;
+    }
     return KMC_OK;
 }
 
@@ -273,7 +282,7 @@ int launch_end(kmc_ctx* c) {
 }
 
 int launch_stream(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases,
-                  u64 chunk_begin, u64 chunk_end) {
+                  u64 chunk_begin, u64 chunk_end, u64 range_begin) {
     // the kernel indexes chunks from 0; a sub-range is expressed by offsetting the chunk ids
     u64 n_chunks = chunk_end - chunk_begin;
     if (!n_chunks) return KMC_OK;
@@ -287,7 +296,7 @@ int launch_stream(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
     { int rc = launch_begin(c); if (rc) return rc; }
 #define LAUNCH_STREAM(KWV, CAN)                                                                          \
     hipLaunchKernelGGL((kmc_stream_kernel<KWV, CAN>), dim3(grid), dim3(KMC_STREAM_THREADS), 0, c->stream, \
-                       d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, cpw, g)
+                       d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, cpw, range_begin, g)
     if (c->KW == 1) { if (canon) LAUNCH_STREAM(1, true); else LAUNCH_STREAM(1, false); }
     else { if (canon) LAUNCH_STREAM(2, true); else LAUNCH_STREAM(2, false); }
 #undef LAUNCH_STREAM
@@ -346,58 +355,106 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
         rc = launch_end(c);
         if (rc) return rc;
         c->pending = true;
-    } else if (algo == KMC_ALGO_WALK) {
-        size_t ws_bytes = kmc_walk_workspace_bytes(n_reads);
-        rc = ensure(c, c->walk_ws, ws_bytes);
-        if (rc) return rc;
-        if (!c->walk_memo.p || c->walk_overflowed) {
-            // (re)start from an empty memo: first use, or the last batch overflowed it (its entries
-            // were not representative; keeping them would only hold the tables full)
-            rc = ensure(c, c->walk_memo, kmc_walk_memo_bytes(c->n_cu, c->KW));
-            if (rc) return rc;
-            HIPCHK(c, hipMemsetAsync(c->walk_memo.p, 0, kmc_walk_memo_bytes(c->n_cu, c->KW), c->stream));
-        }
-        rc = launch_begin(c);
-        if (rc) return rc;
-        rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_offsets, n_reads, n_bases,
-                             c->walk_ws.p, c->walk_memo.p, gtable_of(c, c->tab));
-        if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-        rc = launch_end(c);
-        if (rc) return rc;
-        c->pending = true;
     } else {
-        // Sub-batches by chunk range.  A sub-batch of n k-mers can add at most n new keys, so the
-        // first one is sized to what the table and spill area can absorb for certain; later ones
-        // ramp up using the observed ratio of new keys per k-mer (x16 per step at most).
-        const u64 n_chunks = (n_bases + KMC_CHUNK - 1) / KMC_CHUNK;
-        u64 done = 0, prev = 0;
-        while (done < n_chunks) {
+        // Sub-batches.  A launch over n k-mers can add at most n new keys, so without history the
+        // first launch is sized to what the table and spill area absorb for certain and later ones
+        // ramp up (x16 at most) using the observed ratio rho = new keys per k-mer.  With history
+        // (the previous batch on this ctx, kept across kmc_reset) the batch goes out in as few
+        // launches as 8 x the predicted number of new keys allows -- one for the benchmark input.
+        // If a prediction is ever wrong enough to exhaust table AND spill area the call fails with
+        // KMC_ERR_CAPACITY (nothing is silently dropped).
+        double batch_rho_max = 0.0;
+        c->b_occ0 = c->h_counters[KMC_CTR_OCCUPIED];
+        c->b_kmers = std::max<u64>(n_bases, 1);
+        auto plan = [&](u64 units_left, u64 kmers_per_unit, u64 prev) -> u64 {
             u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
             u64 freeslots = (c->tab.cap * 7 / 10 > occ ? c->tab.cap * 7 / 10 - occ : 0) + c->spill_cap / 2;
-            u64 safe = std::max<u64>(freeslots / KMC_CHUNK, 1);
+            u64 safe = std::max<u64>(freeslots / kmers_per_unit, 1);
             u64 take = safe;
             if (prev) {
-                double rho = std::max(c->rho_last, 1e-9);
-                double opt = (double)freeslots / (4.0 * rho) / KMC_CHUNK;
-                u64 ramp = prev * 16;
-                take = std::max<u64>(safe, (u64)std::min<double>(opt, (double)ramp));
+                double opt = (double)freeslots / (4.0 * std::max(c->rho_last, 1e-9)) / (double)kmers_per_unit;
+                take = std::max<u64>(safe, (u64)std::min<double>(opt, (double)prev * 16.0));
+            } else if (c->rho_hist >= 0.0) {
+                double opt = (double)freeslots / (8.0 * std::max(c->rho_hist, 1e-9)) / (double)kmers_per_unit;
+                take = std::max<u64>(safe, (u64)std::min<double>(opt, 1e18));
             }
-            take = std::min<u64>(take, n_chunks - done);
-            rc = launch_stream(c, d_bases, d_offsets, n_reads, n_bases, done, done + take);
+            return std::min<u64>(take, units_left);
+        };
+        auto observe = [&](u64 occ_before, u64 units, u64 kmers_per_unit) -> int {
+            int r = poll_and_settle(c);
+            if (r) return r;
+            u64 occ_after = c->h_counters[KMC_CTR_OCCUPIED];
+            double rho = (double)(occ_after > occ_before ? occ_after - occ_before : 0) / ((double)units * (double)kmers_per_unit);
+            c->rho_last = rho;
+            c->rho_max = std::max(c->rho_max, rho);
+            batch_rho_max = std::max(batch_rho_max, rho);
+            return KMC_OK;
+        };
+        u64 stream_from = 0;  // base position from which the stream kernel takes over
+        bool run_stream = (algo != KMC_ALGO_WALK);
+        if (algo == KMC_ALGO_WALK) {
+            size_t ws_bytes = kmc_walk_workspace_bytes(n_reads);
+            rc = ensure(c, c->walk_ws, ws_bytes);
             if (rc) return rc;
-            c->pending = true;
-            done += take;
-            prev = take;
-            if (done < n_chunks) {
-                u64 occ_before = occ;
-                rc = poll_and_settle(c);
+            if (!c->walk_memo.p || c->walk_overflowed) {
+                // (re)start from an empty memo: first use, or the last batch overflowed it (its entries
+                // were not representative; keeping them would only hold the tables full)
+                rc = ensure(c, c->walk_memo, kmc_walk_memo_bytes(c->n_cu, c->KW));
                 if (rc) return rc;
-                u64 occ_after = c->h_counters[KMC_CTR_OCCUPIED];
-                double rho = (double)(occ_after > occ_before ? occ_after - occ_before : 0) / ((double)take * KMC_CHUNK);
-                c->rho_max = std::max(c->rho_max, rho);
-                c->rho_last = rho;
+                HIPCHK(c, hipMemsetAsync(c->walk_memo.p, 0, kmc_walk_memo_bytes(c->n_cu, c->KW), c->stream));
+                c->walk_overflowed = false;
+            }
+            const u64 n_tiles = (n_reads + 63) / 64;
+            const u64 kpt = 64 * std::max<u64>(max_read_len, 1);  // k-mers per tile, upper bound
+            u64 done = 0, prev = 0;
+            while (done < n_tiles) {
+                u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
+                u64 take = plan(n_tiles - done, kpt, prev);
+                rc = launch_begin(c);
+                if (rc) return rc;
+                rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_offsets, n_reads, n_bases,
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, gtable_of(c, c->tab));
+                if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = launch_end(c);
+                if (rc) return rc;
+                c->pending = true;
+                done += take;
+                prev = take;
+                if (done < n_tiles) {
+                    rc = observe(occ, take, kpt);
+                    if (rc) return rc;
+                    if (c->cfg.algo == KMC_ALGO_AUTO && c->walk_overflowed) {
+                        // the memo does not help on this input: hand the rest of the batch to the stream kernel
+                        u64 pos = 0;
+                        HIPCHK(c, hipMemcpyAsync(&pos, d_offsets + done * 64, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        stream_from = pos;
+                        run_stream = true;
+                        c->st.algo_last = KMC_ALGO_STREAM;
+                        break;
+                    }
+                }
             }
         }
+        if (run_stream) {
+            const u64 n_chunks = (n_bases + KMC_CHUNK - 1) / KMC_CHUNK;
+            u64 done = stream_from / KMC_CHUNK, prev = 0;
+            while (done < n_chunks) {
+                u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
+                u64 take = plan(n_chunks - done, KMC_CHUNK, prev);
+                rc = launch_stream(c, d_bases, d_offsets, n_reads, n_bases, done, done + take, stream_from);
+                if (rc) return rc;
+                c->pending = true;
+                done += take;
+                prev = take;
+                if (done < n_chunks) {
+                    rc = observe(occ, take, KMC_CHUNK);
+                    if (rc) return rc;
+                }
+            }
+        }
+        c->b_rho_max = batch_rho_max;  // the last launch's share is folded in by the next poll()
+        c->b_open = true;
     }
     HIPCHK(c, hipEventRecord(c->ev1, c->stream));
     c->timed = true;
@@ -525,6 +582,7 @@ extern "C" int kmc_reset(kmc_ctx* c) {
     c->sorted_valid = false;
     c->n_sorted = 0;
     c->direct_seen = c->kmers_seen = 0;
+    c->b_open = false;  // (rho_hist itself is kept: it describes the data source)
     u64 cap = c->st.table_capacity;
     c->st = kmc_stats{};
     c->st.table_capacity = cap;

@@ -118,7 +118,7 @@ __device__ __forceinline__ WMask<KW> smear(WMask<KW> m, int t) {
 template <int KW, bool CANON>
 __global__ __launch_bounds__(KMC_STREAM_THREADS)
 void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets,
-                       u64 n_reads, int k, u64 chunk_begin, u64 chunk_end, u64 chunks_per_wave, GTable g) {
+                       u64 n_reads, int k, u64 chunk_begin, u64 chunk_end, u64 chunks_per_wave, u64 range_begin, GTable g) {
     constexpr int NW = 2 * KW + 1;  // window words: own + 2*KW preceding lanes
     __shared__ StreamLds<KW> L;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -226,6 +226,10 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                     WMask<KW> Z = WMask<KW>::make(zl, zh), B = WMask<KW>::make(bl, bh);
                     WMask<KW> inv = smear<KW>(Z, k - 1) | B.shl(k - 1);
                     inv16 = inv.bits16_at(16 * (NW - 1));
+                }
+                if (pp < range_begin) {  // windows ending before range_begin belong to an earlier launch
+                    u64 nskip = range_begin - pp;
+                    inv16 |= nskip >= 16 ? 0xFFFFu : ((1u << (u32)nskip) - 1u);
                 }
                 if (inv16 != 0xFFFFu) {
                     // rc stream words from the LSB end: Yw[m] = rc word of lane-(NW-1-m)

@@ -336,7 +336,7 @@ __device__ __forceinline__ u32 walk_encode16(uint4 v, u32& x0, u32& x1, u32& x2,
 template <int KW, bool CANON>
 __global__ __launch_bounds__(KMC_WALK_THREADS)
 void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets, u64 n_reads,
-                     int k, WalkWs* ws, u32* deferred, WalkMemoSlot<KW>* memo_slots, GTable g) {
+                     int k, u64 tile_begin, u64 tile_end, WalkWs* ws, u32* deferred, WalkMemoSlot<KW>* memo_slots, GTable g) {
     extern __shared__ __align__(16) unsigned char walk_smem[];
     WalkLds<KW>& L = *reinterpret_cast<WalkLds<KW>*>(walk_smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -364,8 +364,8 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
 
     u32* stage = L.stage[wv];
     u64 nk = 0, ndirect = 0;
-    const u64 n_tiles = (n_reads + 63) / 64;
-    const u64 gw = (u64)blockIdx.x * KMC_WALK_WAVES + wv;
+    const u64 n_tiles = tile_end;  // this launch covers tiles [tile_begin, tile_end) of 64 reads
+    const u64 gw = tile_begin + (u64)blockIdx.x * KMC_WALK_WAVES + wv;
     const u64 total_waves = (u64)gridDim.x * KMC_WALK_WAVES;
 
     // Per-tile geometry: the wave's 64 reads are the byte range [A, B) of the batch.
@@ -586,30 +586,30 @@ static inline size_t kmc_walk_workspace_bytes(u64 n_reads) { return sizeof(WalkW
 
 template <int KW, bool CANON>
 static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const uint8_t* d_bases, const u64* d_offsets,
-                                     u64 n_reads, u64 n_bases, int k, WalkWs* hdr, u32* list, void* memo, GTable g) {
+                                     u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, void* memo, GTable g) {
     const size_t smem = sizeof(WalkLds<KW>);
     static bool attr = false;  // one flag per instantiation
     if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<KW, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-    hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, hdr, list, (WalkMemoSlot<KW>*)memo, g);
+    hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, tile_begin, tile_end, hdr, list, (WalkMemoSlot<KW>*)memo, g);
     hipLaunchKernelGGL((kmc_scalar_reads_kernel<KW, CANON>), dim3(n_cu), dim3(256), 0, st, d_bases, d_offsets, hdr, list, k, g);
 }
 
 static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool canon, const uint8_t* d_bases,
-                                  const u64* d_offsets, u64 n_reads, u64 n_bases, void* ws, void* memo, GTable g) {
-    if (n_reads >= (1ull << 32)) return KMC_ERR_ARG;
+                                  const u64* d_offsets, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, GTable g) {
+    if (n_reads >= (1ull << 32) || tile_end <= tile_begin) return KMC_ERR_ARG;
     WalkWs* hdr = (WalkWs*)ws;
     u32* list = (u32*)((char*)ws + sizeof(WalkWs));
     if (hipMemsetAsync(hdr, 0, sizeof(WalkWs), st) != hipSuccess) return KMC_ERR_HIP;
-    const u64 n_tiles = (n_reads + 63) / 64;
+    const u64 n_tiles = tile_end - tile_begin;
     u64 want = (n_tiles + KMC_WALK_WAVES - 1) / KMC_WALK_WAVES;
     int grid = (int)(want < (u64)n_cu ? want : (u64)n_cu);  // one 160 KB workgroup per CU is resident
     if (grid < 1) grid = 1;
     if (KW == 1) {
-        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, memo, g);
-        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, memo, g);
+        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g);
+        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g);
     } else {
-        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, memo, g);
-        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, hdr, list, memo, g);
+        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g);
+        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g);
     }
     return hipGetLastError() == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }

@@ -169,6 +169,22 @@ def test_high_cardinality_growth_and_spill(kmc, oracle):
     t, st = _count(kmc, bases, offs, 31, True, kmc.ALGO_STREAM)
     assert t.equals(want)
     assert st.table_capacity >= 2 * want.n_distinct
+    # short reads, every k-mer new: AUTO starts with the walk kernel, sees its memo overflow and hands
+    # the rest of the batch to the stream kernel mid-batch; explicit WALK counts directly, in
+    # sub-batches.  Both stay exact.
+    bases, offs = _random_reads(rng, 40000, 300, 400)
+    for k in (31, 47):
+        want = oracle.count_kmers(bases, offs, k, True, method=1)
+        t, st = _count(kmc, bases, offs, k, True, kmc.ALGO_AUTO)
+        assert t.equals(want) and st.algo_last == kmc.ALGO_STREAM
+        t, st = _count(kmc, bases, offs, k, True, kmc.ALGO_WALK)
+        assert t.equals(want) and st.algo_last == kmc.ALGO_WALK
+        # a second batch on the same ctx goes straight to the stream kernel
+        with kmc.KmerCounter(k=k) as kc:
+            kc.add_batch(bases, offs)
+            kc.add_batch(bases, offs)
+            t2 = kc.export()
+            assert np.array_equal(t2.key_lo, want.key_lo) and np.array_equal(t2.count, 2 * want.count)
 
 
 def test_device_resident_batches_and_synth(kmc, oracle):
