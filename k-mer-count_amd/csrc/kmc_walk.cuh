@@ -386,7 +386,9 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     // starts at A16.  Branch-free on purpose (straight-line code lets the compiler keep counted
     // s_waitcnt vmcnt(N) and two sets in flight): a piece index past the end is clamped to the
     // last piece -- that re-reads one cache line and is never stored.
+    const u64 max_off = (n_bases - 1) & ~15ull;  // never touch a 16-byte piece that starts past the last base
     auto issue4 = [&](uint4 (&v)[4], u64 A16, u32 last, u32 base) {
+        if (A16 > max_off) A16 = max_off;  // (a tile of empty reads at the very end of the batch)
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             u32 p = base + 64 * u + lane;
