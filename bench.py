@@ -87,16 +87,18 @@ def main():
     def step(record):
         kc.reset()
         kc.add_batch_device(d_bases.data_ptr(), d_offs.data_ptr(), n_rec, n_bases, read_len)
-        nd, nt = kc.finalize()
+        if world > 1:
+            owner.reset()
+            kdist.reduce_tables(kc, owner)  # finalizes kc, all-to-all, merge, finalizes owner
+            nd, nt = kc.stats().n_distinct, kc.stats().n_kmers
+        else:
+            nd, nt = kc.finalize()
         if nt != n_kmers:
             raise SystemExit(f"count mismatch: table sums to {nt}, expected {n_kmers}")
         if record:
             st = kc.stats()
             kernel_ms.append(st.kernel_ms_last)
             launches.append(st.launches_last)
-        if world > 1:
-            owner.reset()
-            kdist.reduce_tables(kc, owner)
         return nd
 
     def fence():

@@ -71,6 +71,8 @@ struct kmc_ctx {
     size_t lev_used = 0;
     kmc_stats st{};
     bool timed = false;    // ev0/ev1 bracket a finished batch
+    bool batch_pending = false;  // a COUNT kernel (unknown number of new keys) is queued since the last poll
+    u64 unpolled_adds = 0;       // upper bound of keys added by merge kernels since the last poll
     bool walk_overflowed = false;  // the last WALK batch counted >5% of its k-mers directly
     u64 direct_seen = 0, kmers_seen = 0;
     bool pending = false;  // a batch has been queued since the last counter poll
@@ -175,6 +177,8 @@ int poll(kmc_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, KMC_CTR_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->pending = false;
+    c->batch_pending = false;
+    c->unpolled_adds = 0;
     {
         // share of k-mers the walk kernel had to count directly since the previous poll
         u64 d = c->h_counters[KMC_CTR_BADBASE], n = c->h_counters[KMC_CTR_KMERS];
@@ -278,6 +282,7 @@ int launch_begin(kmc_ctx* c) {
 int launch_end(kmc_ctx* c) {
     HIPCHK(c, hipEventRecord(c->lev[c->lev_used + 1], c->stream));
     c->lev_used += 2;
+    c->batch_pending = true;
     return KMC_OK;
 }
 
@@ -582,6 +587,8 @@ extern "C" int kmc_reset(kmc_ctx* c) {
     c->sorted_valid = false;
     c->n_sorted = 0;
     c->direct_seen = c->kmers_seen = 0;
+    c->batch_pending = false;
+    c->unpolled_adds = 0;
     c->b_open = false;  // (rho_hist itself is kept: it describes the data source)
     u64 cap = c->st.table_capacity;
     c->st = kmc_stats{};
@@ -627,13 +634,18 @@ extern "C" int kmc_merge_pairs_device(kmc_ctx* c, const void* d_key_hi, const vo
     if (!n) return KMC_OK;
     if (!d_key_lo || !d_count) return fail(c, KMC_ERR_ARG, "null device pointer");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
-    // make room for the worst case (every pair new)
-    u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
-    if ((occ + n) * 2 > c->tab.cap) {
-        int rc = grow_to(c, next_pow2((occ + n) * 2));
-        if (rc) return rc;
+    // make room for the worst case (every pair new).  Merges queued since the last poll are
+    // accounted with their upper bound, so a series of merges (one per peer in the multi-GPU reduce)
+    // needs no host synchronisation in between.
+    if (c->batch_pending || (c->h_counters[KMC_CTR_OCCUPIED] + c->unpolled_adds + n) * 2 > c->tab.cap) {
+        if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
+        u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
+        if ((occ + n) * 2 > c->tab.cap) {
+            int rc = grow_to(c, next_pow2((occ + n) * 2));
+            if (rc) return rc;
+        }
     }
+    c->unpolled_adds += n;
     c->sorted_valid = false;
     GTable g = gtable_of(c, c->tab);
     int grid = grid_for(c, n, 256);

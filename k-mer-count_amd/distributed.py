@@ -91,10 +91,23 @@ def all_to_all_v(send: Sequence[torch.Tensor], group=None) -> List[torch.Tensor]
 
 def exchange_pairs(parts_hi: Optional[Sequence[torch.Tensor]], parts_lo: Sequence[torch.Tensor],
                    parts_cnt: Sequence[torch.Tensor], group=None):
-    """Send partition p of (hi, lo, cnt) to rank p.  Returns per-source lists (hi may be None)."""
-    recv_lo = all_to_all_v(parts_lo, group)
-    recv_cnt = all_to_all_v(parts_cnt, group)
-    recv_hi = all_to_all_v(parts_hi, group) if parts_hi is not None else None
+    """Send partition p of (hi, lo, cnt) to rank p.  The two or three arrays of a partition travel
+    as ONE message ([lo | cnt | hi]), so the whole exchange is one size all-to-all plus one payload
+    all-to-all.  Returns per-source lists (hi is None for one-word keys)."""
+    nw = 3 if parts_hi is not None else 2
+    world = len(parts_lo)
+    send = []
+    for p in range(world):
+        chunks = [parts_lo[p], parts_cnt[p]] + ([parts_hi[p]] if parts_hi is not None else [])
+        send.append(torch.cat(chunks) if parts_lo[p].numel() else parts_lo[p].new_empty(0))
+    recv = all_to_all_v(send, group)
+    recv_lo, recv_cnt, recv_hi = [], [], ([] if parts_hi is not None else None)
+    for t in recv:
+        m = int(t.numel()) // nw
+        recv_lo.append(t[:m])
+        recv_cnt.append(t[m:2 * m])
+        if recv_hi is not None:
+            recv_hi.append(t[2 * m:3 * m])
     return recv_hi, recv_lo, recv_cnt
 
 
