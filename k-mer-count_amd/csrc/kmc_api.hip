@@ -70,6 +70,7 @@ struct kmc_ctx {
     std::vector<hipEvent_t> lev;              // pairs bracketing every count-kernel launch of the batch
     size_t lev_used = 0;
     kmc_stats st{};
+    int fin_parity = 0;    // which OUT/SUM counter pair the next kmc_finalize uses
     bool timed = false;    // ev0/ev1 bracket a finished batch
     bool batch_pending = false;  // a COUNT kernel (unknown number of new keys) is queued since the last poll
     u64 unpolled_adds = 0;       // upper bound of keys added by merge kernels since the last poll
@@ -77,7 +78,7 @@ struct kmc_ctx {
     u64 direct_seen = 0, kmers_seen = 0;
     bool pending = false;  // a batch has been queued since the last counter poll
     double rho_last = 0.0; // same, over the most recent sub-batch
-    double rho_hist = -1.0; // largest sub-batch ratio of the previous batch (< 0: no history); survives kmc_reset
+    double rho_hist = -1.0; // new keys per k-mer of the previous batch as a whole (< 0: no history); survives kmc_reset
     bool b_open = false; double b_rho_max = 0.0; u64 b_occ0 = 0, b_kmers = 0;  // the batch whose last launch is still unobserved
     double rho_max = 0.0;  // largest observed (new distinct) / (k-mers) over a sub-batch
     int n_cu = 256;
@@ -190,8 +191,10 @@ int poll(kmc_ctx* c) {
     if (c->b_open) {
         // history for the next batch's launch plan: new keys per k-mer of the batch just finished
         u64 occ = c->h_counters[KMC_CTR_OCCUPIED] + c->h_counters[KMC_CTR_SPILL];
+        // What limits a launch is the NUMBER of new keys it can bring, so the predictor is the whole
+        // batch's ratio (not the burstiest sub-batch's).
         double whole = (double)(occ > c->b_occ0 ? occ - c->b_occ0 : 0) / (double)c->b_kmers;
-        c->rho_hist = std::max(c->b_rho_max, whole);
+        c->rho_hist = whole;
         c->b_open = false;
     }
     return KMC_OK;
@@ -574,14 +577,14 @@ extern "C" int kmc_create(kmc_ctx** out, const kmc_config* cfg) {
 extern "C" int kmc_reset(kmc_ctx* c) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (c->KW == 2) {
-        HIPCHK(c, hipMemsetAsync(c->tab.hi, 0xFF, c->tab.cap * sizeof(u64), c->stream));
-        HIPCHK(c, hipMemsetAsync(c->tab.lo, 0, c->tab.cap * sizeof(u64), c->stream));
-    } else {
-        HIPCHK(c, hipMemsetAsync(c->tab.lo, 0xFF, c->tab.cap * sizeof(u64), c->stream));
+    {
+        GTable g = gtable_of(c, c->tab);
+        int grid = grid_for(c, c->tab.cap, 256);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g);
+        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g);
+        HIPCHK(c, hipGetLastError());
+        c->fin_parity = 0;
     }
-    HIPCHK(c, hipMemsetAsync(c->tab.cnt, 0, c->tab.cap * sizeof(u64), c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_counters, 0, KMC_CTR_N * sizeof(u64), c->stream));
     memset(c->h_counters, 0, KMC_CTR_N * sizeof(u64));
     c->pending = false;
     c->sorted_valid = false;
@@ -667,16 +670,12 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
     for (DevBuf* b : need) { rc = ensure(c, *b, nb); if (rc) return rc; }
     if (c->KW == 2) { rc = ensure(c, c->o_hi, nb); if (rc) return rc; rc = ensure(c, c->t_hi, nb); if (rc) return rc; }
     if (n) {
-        static_assert(KMC_CTR_SUM == KMC_CTR_OUT + 2 && KMC_CTR_BADBASE == KMC_CTR_OUT + 1, "OUT..SUM are cleared together");
-        {   // clear OUT and SUM (BADBASE, between them, must survive: save/restore is not needed -- it is
-            // only read by poll() deltas, so clear the two words separately)
-            HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_OUT], 0, sizeof(u64), c->stream));
-            HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM], 0, sizeof(u64), c->stream));
-        }
+        const int parity = c->fin_parity;
+        c->fin_parity ^= 1;
         GTable g = gtable_of(c, c->tab);
         int grid = grid_for(c, c->tab.cap, 256);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_compact_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p);
-        else hipLaunchKernelGGL(kmc_compact_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)c->t_hi.p, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_compact_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p, parity);
+        else hipLaunchKernelGGL(kmc_compact_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)c->t_hi.p, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p, parity);
         HIPCHK(c, hipGetLastError());
         int g2 = grid_for(c, n, 256);
         const unsigned kb = 2u * (unsigned)c->klen;
@@ -701,7 +700,7 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
     c->n_sorted = n;
     c->sorted_valid = true;
     c->st.n_distinct = n;
-    c->st.n_kmers = n ? c->h_counters[KMC_CTR_SUM] : 0;
+    c->st.n_kmers = n ? c->h_counters[c->fin_parity ? KMC_CTR_SUM : KMC_CTR_SUM1] : 0;  // (fin_parity was flipped above)
     float ms = 0.f;
     if (c->timed) {
         // kernel time = sum over this batch's count-kernel launches (host polls between

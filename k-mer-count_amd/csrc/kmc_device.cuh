@@ -16,7 +16,9 @@ typedef uint64_t u64;
 
 // counters[] layout (device, u64 each)
 enum { KMC_CTR_OCCUPIED = 0, KMC_CTR_SPILL = 1, KMC_CTR_ERR = 2, KMC_CTR_KMERS = 3, KMC_CTR_MAXLEN = 4,
-       KMC_CTR_OUT = 5, KMC_CTR_BADBASE = 6, KMC_CTR_SUM = 7, KMC_CTR_N = 8 };
+       KMC_CTR_OUT = 5, KMC_CTR_BADBASE = 6, KMC_CTR_SUM = 7,
+       KMC_CTR_OUT1 = 8, KMC_CTR_SUM1 = 9,  // second parity of OUT/SUM: a finalize clears the pair the next one uses
+       KMC_CTR_N = 16 };
 
 // Global (HBM) open-addressing count table.  One-word keys (KW==1, k<=31) use key_lo only and
 // KMC_EMPTY64 as the empty marker (a 62-bit key can never equal it).  Two-word keys (KW==2,

@@ -8,13 +8,18 @@
 // occupied slots -> dense (hi, lo, cnt) arrays, plus the identity permutation for the sort and the
 // sum of all counts (counters[KMC_CTR_SUM]) in the same pass
 template <int KW>
-__global__ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_cnt, u64* out_idx) {
+__global__ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_cnt, u64* out_idx, int parity) {
     const u64 cap = g.capmask + 1;
+    const int c_out = parity ? KMC_CTR_OUT1 : KMC_CTR_OUT, c_sum = parity ? KMC_CTR_SUM1 : KMC_CTR_SUM;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // clear the pair the NEXT finalize will use
+        g.counters[parity ? KMC_CTR_OUT : KMC_CTR_OUT1] = 0;
+        g.counters[parity ? KMC_CTR_SUM : KMC_CTR_SUM1] = 0;
+    }
     u64 sum = 0;
     for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (u64)gridDim.x * blockDim.x) {
         bool occ = (KW == 1) ? (g.key_lo[s] != KMC_EMPTY64) : (g.key_hi[s] != KMC_EMPTY64);
         if (occ) {
-            u64 idx = atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OUT], 1ull);
+            u64 idx = atomicAdd((unsigned long long*)&g.counters[c_out], 1ull);
             if (KW == 2) out_hi[idx] = g.key_hi[s];
             out_lo[idx] = g.key_lo[s];
             const u64 c = g.count[s];
@@ -24,7 +29,18 @@ __global__ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_
         }
     }
     sum = wave_sum_u64(sum);
-    if ((threadIdx.x & 63) == 0 && sum) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_SUM], sum);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd((unsigned long long*)&g.counters[c_sum], sum);
+}
+
+// kmc_reset in one launch: every slot empty, every counter zero
+template <int KW>
+__global__ void kmc_reset_kernel(GTable g) {
+    const u64 cap = g.capmask + 1;
+    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (u64)gridDim.x * blockDim.x) {
+        if (KW == 2) { g.key_hi[s] = KMC_EMPTY64; g.key_lo[s] = 0; } else g.key_lo[s] = KMC_EMPTY64;
+        g.count[s] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < KMC_CTR_N) g.counters[threadIdx.x] = 0;
 }
 
 // re-insert every entry of `old` into `g` (growth)

@@ -547,8 +547,9 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
 // One lane per listed read, byte by byte: reads diverted from the walk kernel (non-ACGT bytes).
 template <int KW, bool CANON>
 __global__ void kmc_scalar_reads_kernel(const uint8_t* __restrict__ bases, const u64* __restrict__ offsets,
-                                        const WalkWs* ws, const u32* __restrict__ list, int k, GTable g) {
+                                        WalkWs* ws, const u32* __restrict__ list, int k, GTable g) {
     const u64 n = ws->n_deferred;
+    if (n == 0) return;  // (the common case; the header is cleared by the host only after a non-empty run)
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
