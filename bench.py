@@ -41,7 +41,7 @@ def main():
     ap.add_argument("--fasta-bytes", type=float, default=10e9, help="size of the synthetic FASTA text per GPU")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--pool", type=int, default=10)
-    ap.add_argument("--algo", default="auto", choices=["auto", "stream", "walk"])
+    ap.add_argument("--algo", default="auto", choices=["auto", "stream", "walk", "sort"])
     ap.add_argument("--forward", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-records", type=int, default=5_000_000, help="bounded CPU-baseline sample (~10-15 s of one core)")
@@ -77,7 +77,7 @@ def main():
     torch.cuda.synchronize()
     k = args.k
     n_kmers = n_rec * (read_len - k + 1)
-    algo = {"auto": kmc.ALGO_AUTO, "stream": kmc.ALGO_STREAM, "walk": kmc.ALGO_WALK}[args.algo]
+    algo = {"auto": kmc.ALGO_AUTO, "stream": kmc.ALGO_STREAM, "walk": kmc.ALGO_WALK, "sort": kmc.ALGO_SORT}[args.algo]
 
     kc = kmc.KmerCounter(k=k, canonical=not args.forward, device=local_rank, algo=algo)
     owner = kmc.KmerCounter(k=k, canonical=not args.forward, device=local_rank) if world > 1 else None
@@ -120,7 +120,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = kc.stats()
-    algo_used = {1: "stream", 2: "walk"}.get(st.algo_last, "?")
+    algo_used = {1: "stream", 2: "walk", 3: "sort"}.get(st.algo_last, "?")
 
     # ---- roofline of the dominant kernel (this rank's launches; every rank runs the same shape) --
     algo_bytes = n_bases + 8 * (n_rec + 1)  # 1 B/base ASCII + the offsets array

@@ -60,9 +60,10 @@ typedef enum kmc_mode {
 } kmc_mode;
 
 typedef enum kmc_algo {
-    KMC_ALGO_AUTO = 0,   /* pick per batch */
+    KMC_ALGO_AUTO = 0,   /* pick per batch: WALK for short reads, SORT once the input proves high-cardinality, else STREAM */
     KMC_ALGO_STREAM = 1, /* per-k-mer LDS partial histogram + global atomics (any input) */
-    KMC_ALGO_WALK = 2    /* memoised successor walk: one LDS lookup per 8 bases (short reads) */
+    KMC_ALGO_WALK = 2,   /* memoised successor walk: one LDS lookup per 16 bases (reads <= 416 bases) */
+    KMC_ALGO_SORT = 3    /* extract every window, device radix sort, run-length (high-cardinality input) */
 } kmc_algo;
 
 typedef struct kmc_config {

@@ -28,7 +28,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libkmc.so")
 
 MODE_CONTIG, MODE_LR = 0, 1
-ALGO_AUTO, ALGO_STREAM, ALGO_WALK = 0, 1, 2
+ALGO_AUTO, ALGO_STREAM, ALGO_WALK, ALGO_SORT = 0, 1, 2, 3
 
 OK = 0
 ERR_ARG, ERR_NO_DEVICE, ERR_HIP, ERR_NOMEM, ERR_IO, ERR_FORMAT, ERR_ALPHABET, ERR_CAPACITY, ERR_STATE = range(-1, -10, -1)

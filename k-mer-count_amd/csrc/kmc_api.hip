@@ -25,6 +25,7 @@
 #include "kmc_table.cuh"
 #include "kmc_walk.cuh"
 #include "kmc_lr.cuh"
+#include "kmc_sort.cuh"
 
 namespace {
 
@@ -64,7 +65,12 @@ struct kmc_ctx {
     bool sorted_valid = false;
     // walk-kernel workspace
     DevBuf walk_ws;
-    DevBuf walk_memo;  // per-workgroup memo slots, kept across launches (kmc_walk.cuh)
+    DevBuf walk_memo;
+    // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
+    DevBuf s_lo[2], s_hi[2], s_flags, s_pos, s_head;
+    struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0; };
+    std::vector<Run> runs;
+    bool prefer_sort = false;  // AUTO: the data source proved high-cardinality  // per-workgroup memo slots, kept across launches (kmc_walk.cuh)
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the whole batch
     std::vector<hipEvent_t> lev;              // pairs bracketing every count-kernel launch of the batch
@@ -118,6 +124,8 @@ void free_buf(DevBuf& b) {
     b.bytes = 0;
 }
 
+void free_runs(kmc_ctx* c);
+
 void free_table(Table& t) {
     if (t.hi) (void)hipFree(t.hi);
     if (t.lo) (void)hipFree(t.lo);
@@ -140,6 +148,15 @@ int alloc_table(kmc_ctx* c, Table& t, u64 cap) {
     }
     HIPCHK(c, hipMemsetAsync(t.cnt, 0, cap * sizeof(u64), c->stream));
     return KMC_OK;
+}
+
+void free_runs(kmc_ctx* c) {
+    for (auto& r : c->runs) {
+        if (r.hi) (void)hipFree(r.hi);
+        if (r.lo) (void)hipFree(r.lo);
+        if (r.cnt) (void)hipFree(r.cnt);
+    }
+    c->runs.clear();
 }
 
 GTable gtable_of(const kmc_ctx* c, const Table& t) {
@@ -302,14 +319,161 @@ int launch_stream(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
     GTable g = gtable_of(c, c->tab);
     const bool canon = c->cfg.canonical != 0;
     { int rc = launch_begin(c); if (rc) return rc; }
-#define LAUNCH_STREAM(KWV, CAN)                                                                          \
-    hipLaunchKernelGGL((kmc_stream_kernel<KWV, CAN>), dim3(grid), dim3(KMC_STREAM_THREADS), 0, c->stream, \
-                       d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, cpw, range_begin, g)
+#define LAUNCH_STREAM(KWV, CAN)                                                                             \
+    hipLaunchKernelGGL((kmc_stream_kernel<KWV, CAN, 0>), dim3(grid), dim3(KMC_STREAM_THREADS), 0, c->stream, \
+                       d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, cpw, range_begin, g, (u64*)nullptr, (u64*)nullptr)
     if (c->KW == 1) { if (canon) LAUNCH_STREAM(1, true); else LAUNCH_STREAM(1, false); }
     else { if (canon) LAUNCH_STREAM(2, true); else LAUNCH_STREAM(2, false); }
 #undef LAUNCH_STREAM
     HIPCHK(c, hipGetLastError());
     return launch_end(c);
+}
+
+// ---- KMC_ALGO_SORT -------------------------------------------------------------------------------
+
+// extraction front end: one key per base position of chunks [chunk_begin, chunk_end)
+int launch_extract(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases,
+                   u64 chunk_begin, u64 chunk_end, u64 range_begin, u64* out_hi, u64* out_lo) {
+    u64 n_chunks = chunk_end - chunk_begin;
+    if (!n_chunks) return KMC_OK;
+    u64 max_waves = (u64)c->n_cu * 4 * KMC_STREAM_WAVES;  // 2 workgroups per CU resident (no LDS table), 2 rounds
+    u64 cpw = (n_chunks + max_waves - 1) / max_waves;
+    if (cpw < 4) cpw = std::min<u64>(4, n_chunks);
+    u64 waves = (n_chunks + cpw - 1) / cpw;
+    int grid = (int)((waves + KMC_STREAM_WAVES - 1) / KMC_STREAM_WAVES);
+    GTable g = gtable_of(c, c->tab);
+    const bool canon = c->cfg.canonical != 0;
+    { int rc = launch_begin(c); if (rc) return rc; }
+#define LAUNCH_EXTRACT(KWV, CAN)                                                                             \
+    hipLaunchKernelGGL((kmc_stream_kernel<KWV, CAN, 1>), dim3(grid), dim3(KMC_STREAM_THREADS), 0, c->stream, \
+                       d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, cpw, range_begin, g, out_hi, out_lo)
+    if (c->KW == 1) { if (canon) LAUNCH_EXTRACT(1, true); else LAUNCH_EXTRACT(1, false); }
+    else { if (canon) LAUNCH_EXTRACT(2, true); else LAUNCH_EXTRACT(2, false); }
+#undef LAUNCH_EXTRACT
+    HIPCHK(c, hipGetLastError());
+    return launch_end(c);
+}
+
+template <typename K, typename V>
+int sort_pairs_kv(kmc_ctx* c, const K* kin, K* kout, const V* vin, V* vout, u64 n, unsigned bits) {
+    size_t tmp = 0;
+    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, (size_t)n, 0u, bits, c->stream));
+    int rc = ensure(c, c->sort_tmp, tmp);
+    if (rc) return rc;
+    HIPCHK(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, kin, kout, vin, vout, (size_t)n, 0u, bits, c->stream));
+    return KMC_OK;
+}
+
+int sort_keys_k(kmc_ctx* c, const u64* kin, u64* kout, u64 n, unsigned bits) {
+    size_t tmp = 0;
+    HIPCHK(c, rocprim::radix_sort_keys(nullptr, tmp, kin, kout, (size_t)n, 0u, bits, c->stream));
+    int rc = ensure(c, c->sort_tmp, tmp);
+    if (rc) return rc;
+    HIPCHK(c, rocprim::radix_sort_keys(c->sort_tmp.p, tmp, kin, kout, (size_t)n, 0u, bits, c->stream));
+    return KMC_OK;
+}
+
+// Collapse n sorted keys (hi may be null for one-word keys) into runs.  cnt_in == nullptr: run
+// length is the count (fresh occurrences); otherwise the counts of equal keys are summed
+// (merging already counted pairs).  A trailing all-ones run (positions without a valid window) is
+// dropped when drop_sentinel is set.  The result is appended to c->runs (exact-size buffers).
+int collapse_runs(kmc_ctx* c, const u64* hi, const u64* lo, const u64* cnt_in, u64 n, bool drop_sentinel) {
+    if (!n) return KMC_OK;
+    if (n >= (1ull << 32)) return fail(c, KMC_ERR_ARG, "collapse_runs: more than 2^32-1 elements in one pass");
+    int rc = ensure(c, c->s_flags, (size_t)n * sizeof(u32));
+    if (rc) return rc;
+    rc = ensure(c, c->s_pos, (size_t)n * sizeof(u32));
+    if (rc) return rc;
+    u32* flags = (u32*)c->s_flags.p;
+    u32* pos = (u32*)c->s_pos.p;
+    const int g = grid_for(c, n, 256);
+    if (c->KW == 1) hipLaunchKernelGGL(kmc_run_flags_kernel<1>, dim3(g), dim3(256), 0, c->stream, hi, lo, n, flags);
+    else hipLaunchKernelGGL(kmc_run_flags_kernel<2>, dim3(g), dim3(256), 0, c->stream, hi, lo, n, flags);
+    HIPCHK(c, hipGetLastError());
+    size_t tmp = 0;
+    HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp, flags, pos, 0u, (size_t)n, rocprim::plus<u32>(), c->stream));
+    rc = ensure(c, c->sort_tmp, tmp);
+    if (rc) return rc;
+    HIPCHK(c, rocprim::exclusive_scan(c->sort_tmp.p, tmp, flags, pos, 0u, (size_t)n, rocprim::plus<u32>(), c->stream));
+    u32 last_pos = 0, last_flag = 0;
+    u64 last_lo = 0, last_hi = 0;
+    HIPCHK(c, hipMemcpyAsync(&last_pos, pos + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&last_flag, flags + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&last_lo, lo + (n - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    if (hi) HIPCHK(c, hipMemcpyAsync(&last_hi, hi + (n - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const u64 n_runs = (u64)last_pos + last_flag;
+    const bool last_is_sentinel = drop_sentinel && (c->KW == 2 ? last_hi == ~0ull : last_lo == ~0ull);
+    const u64 keep = n_runs - (last_is_sentinel ? 1 : 0);
+    kmc_ctx::Run run;
+    run.n = keep;
+    HIPCHK(c, hipMalloc((void**)&run.lo, std::max<u64>(n_runs, 1) * sizeof(u64)));
+    HIPCHK(c, hipMalloc((void**)&run.cnt, std::max<u64>(n_runs, 1) * sizeof(u64)));
+    if (c->KW == 2) HIPCHK(c, hipMalloc((void**)&run.hi, std::max<u64>(n_runs, 1) * sizeof(u64)));
+    c->runs.push_back(run);  // owned from here on (freed by free_runs even if a later step fails)
+    rc = ensure(c, c->s_head, (size_t)(n_runs + 1) * sizeof(u64));
+    if (rc) return rc;
+    u64* head = (u64*)c->s_head.p;
+    if (c->KW == 1) hipLaunchKernelGGL(kmc_run_heads_kernel<1>, dim3(g), dim3(256), 0, c->stream, hi, lo, n, flags, pos, run.hi, run.lo, head);
+    else hipLaunchKernelGGL(kmc_run_heads_kernel<2>, dim3(g), dim3(256), 0, c->stream, hi, lo, n, flags, pos, run.hi, run.lo, head);
+    if (cnt_in) {
+        HIPCHK(c, hipMemsetAsync(run.cnt, 0, std::max<u64>(n_runs, 1) * sizeof(u64), c->stream));
+        hipLaunchKernelGGL(kmc_run_sums_kernel, dim3(g), dim3(256), 0, c->stream, flags, pos, cnt_in, n, run.cnt);
+    } else {
+        hipLaunchKernelGGL(kmc_run_lengths_kernel, dim3(grid_for(c, n_runs, 256)), dim3(256), 0, c->stream, head, n_runs, n, run.cnt);
+    }
+    HIPCHK(c, hipGetLastError());
+    if (!keep) {  // nothing valid in this pass: drop the empty run again
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        kmc_ctx::Run r = c->runs.back();
+        c->runs.pop_back();
+        if (r.hi) (void)hipFree(r.hi);
+        (void)hipFree(r.lo);
+        (void)hipFree(r.cnt);
+    }
+    return KMC_OK;
+}
+
+// Sort n keys held in c->s_lo[0] (and c->s_hi[0]); returns the index (0/1) of the buffers holding the result.
+int sort_keys_buffers(kmc_ctx* c, u64 n, int* where) {
+    const unsigned kb = 2u * (unsigned)c->klen;
+    if (c->KW == 1) {
+        // two bits above the key so that the all-ones filler sorts strictly last
+        int rc = sort_keys_k(c, (const u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p, n, std::min(64u, kb + 2u));
+        *where = 1;
+        return rc;
+    }
+    // LSD over two words: by lo carrying hi, then (stable) by all of hi carrying lo
+    int rc = sort_pairs_kv<u64, u64>(c, (const u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p, (const u64*)c->s_hi[0].p, (u64*)c->s_hi[1].p, n, 64u);
+    if (rc) return rc;
+    rc = sort_pairs_kv<u64, u64>(c, (const u64*)c->s_hi[1].p, (u64*)c->s_hi[0].p, (const u64*)c->s_lo[1].p, (u64*)c->s_lo[0].p, n, 64u);
+    *where = 0;
+    return rc;
+}
+
+// Count the windows ending in [range_begin, n_bases) by extract -> sort -> run-length, in sub-batches
+// of at most 2^29 base positions (8-16 GiB of keys in flight).  Each sub-batch leaves one run.
+int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 range_begin) {
+    const u64 n_chunks = (n_bases + KMC_CHUNK - 1) / KMC_CHUNK;
+    const u64 SB = 1ull << 19;  // chunks per sub-batch
+    for (u64 cb = range_begin / KMC_CHUNK; cb < n_chunks; cb += SB) {
+        const u64 ce = std::min(n_chunks, cb + SB);
+        const u64 n = (ce - cb) * KMC_CHUNK;
+        for (int i = 0; i < 2; ++i) {
+            int rc = ensure(c, c->s_lo[i], (size_t)n * sizeof(u64));
+            if (rc) return rc;
+            if (c->KW == 2) { rc = ensure(c, c->s_hi[i], (size_t)n * sizeof(u64)); if (rc) return rc; }
+        }
+        int rc = launch_extract(c, d_bases, d_offsets, n_reads, n_bases, cb, ce, range_begin, (u64*)c->s_hi[0].p, (u64*)c->s_lo[0].p);
+        if (rc) return rc;
+        int w = 0;
+        rc = sort_keys_buffers(c, n, &w);
+        if (rc) return rc;
+        rc = collapse_runs(c, c->KW == 2 ? (const u64*)c->s_hi[w].p : nullptr, (const u64*)c->s_lo[w].p, nullptr, n, true);
+        if (rc) return rc;
+    }
+    c->pending = true;
+    return KMC_OK;
 }
 
 int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len) {
@@ -321,7 +485,8 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     if (!n_reads || !n_bases) return KMC_OK;
 
     int algo = c->cfg.algo;
-    if (c->cfg.mode == KMC_MODE_LR) algo = KMC_ALGO_STREAM;  // LR runs its own kernel inside walk.cuh
+    if (c->cfg.mode == KMC_MODE_LR) algo = KMC_ALGO_STREAM;  // LR runs its own kernel (kmc_lr.cuh)
+    if (algo == KMC_ALGO_AUTO && c->prefer_sort) algo = KMC_ALGO_SORT;
     if (algo == KMC_ALGO_AUTO || algo == KMC_ALGO_WALK) {
         if (!max_read_len) {
             HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_MAXLEN], 0, sizeof(u64), c->stream));
@@ -398,8 +563,10 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             batch_rho_max = std::max(batch_rho_max, rho);
             return KMC_OK;
         };
-        u64 stream_from = 0;  // base position from which the stream kernel takes over
-        bool run_stream = (algo != KMC_ALGO_WALK);
+        u64 stream_from = 0;  // base position from which the stream / sort path takes over
+        bool run_stream = (algo == KMC_ALGO_STREAM);
+        bool run_sort = (algo == KMC_ALGO_SORT);
+        const bool is_auto = c->cfg.algo == KMC_ALGO_AUTO;
         if (algo == KMC_ALGO_WALK) {
             size_t ws_bytes = kmc_walk_workspace_bytes(n_reads);
             rc = ensure(c, c->walk_ws, ws_bytes);
@@ -432,13 +599,15 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                     rc = observe(occ, take, kpt);
                     if (rc) return rc;
                     if (c->cfg.algo == KMC_ALGO_AUTO && c->walk_overflowed) {
-                        // the memo does not help on this input: hand the rest of the batch to the stream kernel
+                        // the memo does not help on this input (almost every k-mer is new): hand the rest
+                        // of the batch to the sort path
                         u64 pos = 0;
                         HIPCHK(c, hipMemcpyAsync(&pos, d_offsets + done * 64, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
                         HIPCHK(c, hipStreamSynchronize(c->stream));
                         stream_from = pos;
-                        run_stream = true;
-                        c->st.algo_last = KMC_ALGO_STREAM;
+                        run_sort = true;
+                        c->prefer_sort = true;
+                        c->st.algo_last = KMC_ALGO_SORT;
                         break;
                     }
                 }
@@ -458,8 +627,20 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 if (done < n_chunks) {
                     rc = observe(occ, take, KMC_CHUNK);
                     if (rc) return rc;
+                    if (is_auto && c->rho_last > 0.2) {
+                        // more than one new key per five k-mers: per-occurrence hashing is the wrong tool
+                        stream_from = done * KMC_CHUNK;
+                        run_sort = true;
+                        c->prefer_sort = true;
+                        c->st.algo_last = KMC_ALGO_SORT;
+                        break;
+                    }
                 }
             }
+        }
+        if (run_sort) {
+            rc = run_sort_path(c, d_bases, d_offsets, n_reads, n_bases, stream_from);
+            if (rc) return rc;
         }
         c->b_rho_max = batch_rho_max;  // the last launch's share is folded in by the next poll()
         c->b_open = true;
@@ -514,7 +695,9 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     if (c->spill_lo) (void)hipFree(c->spill_lo);
     if (c->spill_cnt) (void)hipFree(c->spill_cnt);
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
-                      &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo};
+                      &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo,
+                      &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->s_flags, &c->s_pos, &c->s_head};
+    free_runs(c);
     for (DevBuf* b : bufs) free_buf(*b);
     for (hipEvent_t e : c->lev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -529,7 +712,7 @@ extern "C" int kmc_create(kmc_ctx** out, const kmc_config* cfg) {
     if (cfg->struct_size != sizeof(kmc_config)) return fail(nullptr, KMC_ERR_ARG, "kmc_config.struct_size mismatch (%u != %zu)", cfg->struct_size, sizeof(kmc_config));
     if (cfg->mode != KMC_MODE_CONTIG && cfg->mode != KMC_MODE_LR) return fail(nullptr, KMC_ERR_ARG, "bad mode %d", cfg->mode);
     if (cfg->mode == KMC_MODE_CONTIG && (cfg->k < 1 || cfg->k > 63)) return fail(nullptr, KMC_ERR_ARG, "k must be in 1..63 (got %d)", cfg->k);
-    if (cfg->algo < KMC_ALGO_AUTO || cfg->algo > KMC_ALGO_WALK) return fail(nullptr, KMC_ERR_ARG, "bad algo %d", cfg->algo);
+    if (cfg->algo < KMC_ALGO_AUTO || cfg->algo > KMC_ALGO_SORT) return fail(nullptr, KMC_ERR_ARG, "bad algo %d", cfg->algo);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) return fail(nullptr, KMC_ERR_NO_DEVICE, "no usable HIP device (%s); libkmc has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
@@ -589,6 +772,7 @@ extern "C" int kmc_reset(kmc_ctx* c) {
     c->pending = false;
     c->sorted_valid = false;
     c->n_sorted = 0;
+    free_runs(c);
     c->direct_seen = c->kmers_seen = 0;
     c->batch_pending = false;
     c->unpolled_adds = 0;
@@ -659,48 +843,112 @@ extern "C" int kmc_merge_pairs_device(kmc_ctx* c, const void* d_key_hi, const vo
     return KMC_OK;
 }
 
+// sort n compacted (hi, lo, cnt) triples held in t_* into o_* (duplicates, if any, stay adjacent)
+static int sort_view(kmc_ctx* c, u64 n) {
+    int rc;
+    const int g2 = grid_for(c, n, 256);
+    const unsigned kb = 2u * (unsigned)c->klen;
+    if (c->KW == 1) {
+        rc = sort_pairs<u64>(c, (const u64*)c->t_lo.p, (u64*)c->o_lo.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, std::max(kb, 1u));
+        if (rc) return rc;
+        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_cnt.p, (const u64*)c->t_idx1.p, (u64*)c->o_cnt.p, n);
+    } else {
+        // LSD over two words: stable sort by lo, then by hi
+        rc = sort_pairs<u64>(c, (const u64*)c->t_lo.p, (u64*)c->t_key.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, 64u);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_hi.p, (const u64*)c->t_idx1.p, (u64*)c->t_key.p, n);
+        rc = sort_pairs<u64>(c, (const u64*)c->t_key.p, (u64*)c->o_hi.p, (const u64*)c->t_idx1.p, (u64*)c->t_idx0.p, n, kb > 64 ? kb - 64 : 1u);
+        if (rc) return rc;
+        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_lo.p, (const u64*)c->t_idx0.p, (u64*)c->o_lo.p, n);
+        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_cnt.p, (const u64*)c->t_idx0.p, (u64*)c->o_cnt.p, n);
+    }
+    HIPCHK(c, hipGetLastError());
+    return KMC_OK;
+}
+
 extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc = poll_and_settle(c);
     if (rc) return rc;
-    const u64 n = c->h_counters[KMC_CTR_OCCUPIED];
+    const u64 n_tab = c->h_counters[KMC_CTR_OCCUPIED];
+    u64 n_runs_total = 0;
+    for (auto& r : c->runs) n_runs_total += r.n;
+    u64 n = n_tab + n_runs_total;  // entries before merging duplicates across sources
+    u64 n_kmers = 0;
     const size_t nb = (size_t)std::max<u64>(n, 1) * sizeof(u64);
     DevBuf* need[] = {&c->o_lo, &c->o_cnt, &c->t_lo, &c->t_cnt, &c->t_idx0, &c->t_idx1, &c->t_key};
     for (DevBuf* b : need) { rc = ensure(c, *b, nb); if (rc) return rc; }
     if (c->KW == 2) { rc = ensure(c, c->o_hi, nb); if (rc) return rc; rc = ensure(c, c->t_hi, nb); if (rc) return rc; }
-    if (n) {
-        const int parity = c->fin_parity;
-        c->fin_parity ^= 1;
-        GTable g = gtable_of(c, c->tab);
-        int grid = grid_for(c, c->tab.cap, 256);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_compact_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p, parity);
-        else hipLaunchKernelGGL(kmc_compact_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)c->t_hi.p, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p, parity);
-        HIPCHK(c, hipGetLastError());
-        int g2 = grid_for(c, n, 256);
-        const unsigned kb = 2u * (unsigned)c->klen;
-        if (c->KW == 1) {
-            rc = sort_pairs<u64>(c, (const u64*)c->t_lo.p, (u64*)c->o_lo.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, std::max(kb, 1u));
-            if (rc) return rc;
-            hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_cnt.p, (const u64*)c->t_idx1.p, (u64*)c->o_cnt.p, n);
-        } else {
-            // LSD over two words: stable sort by lo, then by hi
-            rc = sort_pairs<u64>(c, (const u64*)c->t_lo.p, (u64*)c->t_key.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, 64u);
-            if (rc) return rc;
-            hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_hi.p, (const u64*)c->t_idx1.p, (u64*)c->t_key.p, n);
-            rc = sort_pairs<u64>(c, (const u64*)c->t_key.p, (u64*)c->o_hi.p, (const u64*)c->t_idx1.p, (u64*)c->t_idx0.p, n, kb > 64 ? kb - 64 : 1u);
-            if (rc) return rc;
-            hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_lo.p, (const u64*)c->t_idx0.p, (u64*)c->o_lo.p, n);
-            hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_cnt.p, (const u64*)c->t_idx0.p, (u64*)c->o_cnt.p, n);
-        }
+    const bool single_run = n_tab == 0 && c->runs.size() == 1;
+    if (single_run) {
+        // one sorted run and an empty table: it IS the sorted view
+        auto& r = c->runs[0];
+        HIPCHK(c, hipMemcpyAsync(c->o_lo.p, r.lo, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->o_cnt.p, r.cnt, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        if (c->KW == 2) HIPCHK(c, hipMemcpyAsync(c->o_hi.p, r.hi, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM2], 0, sizeof(u64), c->stream));
+        hipLaunchKernelGGL(kmc_sum_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, (const u64*)c->o_cnt.p, n, c->d_counters);
         HIPCHK(c, hipGetLastError());
         rc = poll(c);
         if (rc) return rc;
+        n_kmers = c->h_counters[KMC_CTR_SUM2];
+    } else if (n) {
+        if (n_tab) {
+            const int parity = c->fin_parity;
+            c->fin_parity ^= 1;
+            GTable g = gtable_of(c, c->tab);
+            int grid = grid_for(c, c->tab.cap, 256);
+            if (c->KW == 1) hipLaunchKernelGGL(kmc_compact_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p, parity);
+            else hipLaunchKernelGGL(kmc_compact_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)c->t_hi.p, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p, parity);
+            HIPCHK(c, hipGetLastError());
+        }
+        if (c->runs.empty()) {
+            rc = sort_view(c, n);
+            if (rc) return rc;
+            rc = poll(c);
+            if (rc) return rc;
+            n_kmers = c->h_counters[c->fin_parity ? KMC_CTR_SUM : KMC_CTR_SUM1];  // (fin_parity was flipped above)
+        } else {
+            // table entries + every run, concatenated, sorted, equal keys summed
+            u64 off = n_tab;
+            for (auto& r : c->runs) {
+                HIPCHK(c, hipMemcpyAsync((u64*)c->t_lo.p + off, r.lo, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync((u64*)c->t_cnt.p + off, r.cnt, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+                if (c->KW == 2) HIPCHK(c, hipMemcpyAsync((u64*)c->t_hi.p + off, r.hi, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+                off += r.n;
+            }
+            hipLaunchKernelGGL(kmc_iota_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, (u64*)c->t_idx0.p, n);
+            rc = sort_view(c, n);
+            if (rc) return rc;
+            const size_t before = c->runs.size();
+            rc = collapse_runs(c, c->KW == 2 ? (const u64*)c->o_hi.p : nullptr, (const u64*)c->o_lo.p, (const u64*)c->o_cnt.p, n, false);
+            if (rc) return rc;
+            if (c->runs.size() > before) {
+                kmc_ctx::Run m = c->runs.back();
+                c->runs.pop_back();
+                n = m.n;
+                HIPCHK(c, hipMemcpyAsync(c->o_lo.p, m.lo, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->o_cnt.p, m.cnt, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+                if (c->KW == 2) HIPCHK(c, hipMemcpyAsync(c->o_hi.p, m.hi, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM2], 0, sizeof(u64), c->stream));
+                hipLaunchKernelGGL(kmc_sum_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, (const u64*)c->o_cnt.p, n, c->d_counters);
+                HIPCHK(c, hipGetLastError());
+                rc = poll(c);
+                if (m.hi) (void)hipFree(m.hi);
+                (void)hipFree(m.lo);
+                (void)hipFree(m.cnt);
+                if (rc) return rc;
+                n_kmers = c->h_counters[KMC_CTR_SUM2];
+            } else {
+                n = 0;
+            }
+        }
     }
     c->n_sorted = n;
     c->sorted_valid = true;
     c->st.n_distinct = n;
-    c->st.n_kmers = n ? c->h_counters[c->fin_parity ? KMC_CTR_SUM : KMC_CTR_SUM1] : 0;  // (fin_parity was flipped above)
+    c->st.n_kmers = n ? n_kmers : 0;
     float ms = 0.f;
     if (c->timed) {
         // kernel time = sum over this batch's count-kernel launches (host polls between

@@ -4,7 +4,7 @@
 // cwd (main.rs:44) and prints one sorted 54-character line per occurrence (main.rs:88-90);
 // test.py:15-18 takes the FASTA path as its only positional argument.  This tool keeps both:
 //
-//   k-mer-count [FASTA] [-k K] [--forward] [--expand] [--device N] [--algo auto|stream|walk] [--stats]
+//   k-mer-count [FASTA] [-k K] [--forward] [--expand] [--device N] [--algo auto|stream|walk|sort] [--stats]
 //
 //   no -k   reference mode: LR-gapped 27+gap+27 for sizes 80..=140, expanded sorted output,
 //           byte-identical to main.rs:87-90
@@ -37,9 +37,9 @@ int main(int argc, char** argv) {
         else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
         else if (a == "--algo" && i + 1 < argc) {
             std::string v = argv[++i];
-            algo = v == "stream" ? KMC_ALGO_STREAM : v == "walk" ? KMC_ALGO_WALK : KMC_ALGO_AUTO;
+            algo = v == "stream" ? KMC_ALGO_STREAM : v == "walk" ? KMC_ALGO_WALK : v == "sort" ? KMC_ALGO_SORT : KMC_ALGO_AUTO;
         } else if (a == "-h" || a == "--help") {
-            fprintf(stderr, "usage: k-mer-count [FASTA] [-k K] [--forward] [--expand] [--device N] [--algo auto|stream|walk] [--stats]\n");
+            fprintf(stderr, "usage: k-mer-count [FASTA] [-k K] [--forward] [--expand] [--device N] [--algo auto|stream|walk|sort] [--stats]\n");
             return 0;
         } else if (!a.empty() && a[0] != '-') path = argv[i];
         else { fprintf(stderr, "k-mer-count: unknown option %s\n", a.c_str()); return 2; }

@@ -115,20 +115,34 @@ __device__ __forceinline__ WMask<KW> smear(WMask<KW> m, int t) {
     return m;
 }
 
-template <int KW, bool CANON>
+// LDS of the extract-only variant (SINK == 1): just the per-wave read-start bitmaps
+struct StreamLdsLite {
+    u32 sbits[KMC_STREAM_WAVES][64];
+};
+template <int KW, int SINK> struct StreamLdsSel { typedef StreamLds<KW> type; };
+template <int KW> struct StreamLdsSel<KW, 1> { typedef StreamLdsLite type; };
+
+// SINK == 0: count into the LDS / global tables (KMC_ALGO_STREAM).
+// SINK == 1: extraction only (front end of KMC_ALGO_SORT): write ONE key per base position of the
+//            launch's chunk range to out_lo/out_hi -- the k-mer ending there, or all-ones where no
+//            valid window ends -- 16 consecutive keys per lane, fully coalesced, no atomics.
+template <int KW, bool CANON, int SINK>
 __global__ __launch_bounds__(KMC_STREAM_THREADS)
 void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets,
-                       u64 n_reads, int k, u64 chunk_begin, u64 chunk_end, u64 chunks_per_wave, u64 range_begin, GTable g) {
+                       u64 n_reads, int k, u64 chunk_begin, u64 chunk_end, u64 chunks_per_wave, u64 range_begin, GTable g,
+                       u64* __restrict__ out_hi, u64* __restrict__ out_lo) {
     constexpr int NW = 2 * KW + 1;  // window words: own + 2*KW preceding lanes
-    __shared__ StreamLds<KW> L;
+    __shared__ typename StreamLdsSel<KW, SINK>::type L;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    for (int s = tid; s < StreamLds<KW>::LCAP; s += KMC_STREAM_THREADS) {
-        if (KW == 1) L.lo[s] = KMC_EMPTY64; else { L.hi[s] = KMC_EMPTY64; L.lo[s] = 0; }
-        L.cnt[s] = 0;
+    if constexpr (SINK == 0) {
+        for (int s = tid; s < StreamLds<KW>::LCAP; s += KMC_STREAM_THREADS) {
+            if (KW == 1) L.lo[s] = KMC_EMPTY64; else { L.hi[s] = KMC_EMPTY64; L.lo[s] = 0; }
+            L.cnt[s] = 0;
+        }
+        if (tid == 0) L.nfill = 0;
+        __syncthreads();
     }
-    if (tid == 0) L.nfill = 0;
-    __syncthreads();
 
     const u64 gw = (u64)blockIdx.x * KMC_STREAM_WAVES + wv;
     // this launch covers chunks [chunk_begin, chunk_end) of the stream (windows ENDING there)
@@ -231,7 +245,7 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                     u64 nskip = range_begin - pp;
                     inv16 |= nskip >= 16 ? 0xFFFFu : ((1u << (u32)nskip) - 1u);
                 }
-                if (inv16 != 0xFFFFu) {
+                if (SINK == 1 || inv16 != 0xFFFFu) {
                     // rc stream words from the LSB end: Yw[m] = rc word of lane-(NW-1-m)
                     u32 Yp[NW + 1];
                     if (CANON) {
@@ -250,8 +264,11 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         }
                         Yp[NW] = 0;
                     }
-                    const bool lds_ok = __hip_atomic_load(&L.nfill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) <
-                                        (u32)(StreamLds<KW>::LCAP * 7 / 8);
+                    bool lds_ok = false;
+                    if constexpr (SINK == 0)
+                        lds_ok = __hip_atomic_load(&L.nfill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (u32)(StreamLds<KW>::LCAP * 7 / 8);
+                    u64* const o_lo = SINK == 1 ? out_lo + (pp - chunk_begin * KMC_CHUNK) : nullptr;
+                    u64* const o_hi = (SINK == 1 && KW == 2) ? out_hi + (pp - chunk_begin * KMC_CHUNK) : nullptr;
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int s = 30 - 2 * j;
@@ -269,9 +286,13 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                             if constexpr (KW == 2) rhi = ((u64)r[3] << 32 | r[2]) & mask_hi;
                             if (key_less(rhi, rlo, fhi, flo)) { klo = rlo; khi = rhi; }
                         }
-                        if (!((inv16 >> j) & 1)) {
-                            lds_add<KW>(L, g, khi, klo, lds_ok);
-                            nk++;
+                        const bool ok = !((inv16 >> j) & 1);
+                        if constexpr (SINK == 0) {
+                            if (ok) { lds_add<KW>(L, g, khi, klo, lds_ok); nk++; }
+                        } else {
+                            o_lo[j] = ok ? klo : ~0ull;
+                            if (KW == 2) o_hi[j] = ok ? khi : ~0ull;
+                            nk += ok;
                         }
                     }
                 }
@@ -283,9 +304,11 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
     nk = wave_sum_u64(nk);
     if (lane == 0 && nk) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_KMERS], nk);
 
-    __syncthreads();
-    for (int s = tid; s < StreamLds<KW>::LCAP; s += KMC_STREAM_THREADS) {
-        u32 c = L.cnt[s];
-        if (c) gtable_add<KW>(g, KW == 2 ? L.hi[s] : 0ull, L.lo[s], c);
+    if constexpr (SINK == 0) {
+        __syncthreads();
+        for (int s = tid; s < StreamLds<KW>::LCAP; s += KMC_STREAM_THREADS) {
+            u32 c = L.cnt[s];
+            if (c) gtable_add<KW>(g, KW == 2 ? L.hi[s] : 0ull, L.lo[s], c);
+        }
     }
 }

@@ -100,10 +100,10 @@ __global__ void kmc_owner_kernel(const u64* hi, const u64* lo, u64 n, u32 n_part
         owner_out[i] = kmc_owner(hi ? hi[i] : 0ull, lo[i], n_parts);
 }
 
-// sum of n counts -> counters[KMC_CTR_SUM]
+// sum of n counts -> counters[KMC_CTR_SUM2]
 __global__ void kmc_sum_kernel(const u64* cnt, u64 n, u64* counters) {
     u64 a = 0;
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) a += cnt[i];
     a = wave_sum_u64(a);
-    if ((threadIdx.x & 63) == 0 && a) atomicAdd((unsigned long long*)&counters[KMC_CTR_SUM], a);
+    if ((threadIdx.x & 63) == 0 && a) atomicAdd((unsigned long long*)&counters[KMC_CTR_SUM2], a);
 }

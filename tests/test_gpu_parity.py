@@ -15,8 +15,8 @@ LR = json.load(open(os.path.join(GOLDEN, "lr_goldens.json")))["cases"]
 
 
 def _algos(kmc, k, max_read_len=None):
-    """Every algorithm that can take this input (WALK: reads <= 416 bases)."""
-    a = [kmc.ALGO_STREAM, kmc.ALGO_AUTO]
+    """Every algorithm that can take this input (WALK: reads <= 416 bases; the others: anything)."""
+    a = [kmc.ALGO_STREAM, kmc.ALGO_AUTO, kmc.ALGO_SORT]
     if k <= 63 and (max_read_len is None or 1 <= max_read_len <= 416):
         a.append(kmc.ALGO_WALK)
     return a
@@ -159,6 +159,23 @@ def test_many_batches_and_reset(kmc, oracle):
         assert kc.export().n_distinct == 0
         kc.add_batch(bases, offs)
         assert kc.export().equals(want)
+    # sorted runs (SORT batches) and hash-table contents (merged pairs) are combined by finalize
+    for k in (21, 63):
+        want = oracle.count_kmers(bases, offs, k, True)
+        with kmc.KmerCounter(k=k, algo=kmc.ALGO_SORT) as kc, kmc.KmerCounter(k=k, algo=kmc.ALGO_STREAM) as other:
+            cuts = np.linspace(0, 3000, 4).astype(int)
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                kc.add_batch(bases[int(offs[a]):int(offs[b])], offs[a:b + 1] - offs[a])
+            assert kc.export().equals(want)           # three runs merged
+            assert kc.export().equals(want)           # finalize is repeatable
+            other.add_batch(bases, offs)
+            other.finalize()
+            dhi, dlo, dcnt, n = other.export_device()
+            kc.merge_pairs_device(dhi, dlo, dcnt, n)  # table part: everything once more
+            t2 = kc.export()
+            assert np.array_equal(t2.key_lo, want.key_lo) and np.array_equal(t2.count, 2 * want.count)
+            kc.reset()
+            assert kc.export().n_distinct == 0
 
 
 def test_high_cardinality_growth_and_spill(kmc, oracle):
@@ -169,17 +186,22 @@ def test_high_cardinality_growth_and_spill(kmc, oracle):
     t, st = _count(kmc, bases, offs, 31, True, kmc.ALGO_STREAM)
     assert t.equals(want)
     assert st.table_capacity >= 2 * want.n_distinct
+    # long reads, AUTO: starts on the stream kernel, sees > 1 new key per 5 k-mers, finishes by sorting
+    t, st = _count(kmc, bases, offs, 31, True, kmc.ALGO_AUTO)
+    assert t.equals(want) and st.algo_last == kmc.ALGO_SORT
+    t, st = _count(kmc, bases, offs, 31, False, kmc.ALGO_SORT)
+    assert t.equals(oracle.count_kmers(bases, offs, 31, False, method=1))
     # short reads, every k-mer new: AUTO starts with the walk kernel, sees its memo overflow and hands
-    # the rest of the batch to the stream kernel mid-batch; explicit WALK counts directly, in
+    # the rest of the batch to the sort path mid-batch; explicit WALK counts directly, in
     # sub-batches.  Both stay exact.
     bases, offs = _random_reads(rng, 40000, 300, 400)
     for k in (31, 47):
         want = oracle.count_kmers(bases, offs, k, True, method=1)
         t, st = _count(kmc, bases, offs, k, True, kmc.ALGO_AUTO)
-        assert t.equals(want) and st.algo_last == kmc.ALGO_STREAM
+        assert t.equals(want) and st.algo_last == kmc.ALGO_SORT
         t, st = _count(kmc, bases, offs, k, True, kmc.ALGO_WALK)
         assert t.equals(want) and st.algo_last == kmc.ALGO_WALK
-        # a second batch on the same ctx goes straight to the stream kernel
+        # a second batch on the same ctx goes straight to the sort path (two sorted runs + table merged)
         with kmc.KmerCounter(k=k) as kc:
             kc.add_batch(bases, offs)
             kc.add_batch(bases, offs)
