@@ -68,8 +68,10 @@ struct kmc_ctx {
     DevBuf walk_memo;
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
     DevBuf s_lo[2], s_hi[2], s_flags, s_pos, s_head;
-    struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0; };
-    std::vector<Run> runs;
+    struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0, cap = 0; };
+    std::vector<Run> runs;       // live runs
+    std::vector<Run> run_pool;   // buffers of dropped runs, reused (multi-GB hipMalloc/hipFree per batch is slow)
+    const u64 *v_hi = nullptr, *v_lo = nullptr, *v_cnt = nullptr;  // the sorted view of the last finalize
     bool prefer_sort = false;  // AUTO: the data source proved high-cardinality  // per-workgroup memo slots, kept across launches (kmc_walk.cuh)
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the whole batch
@@ -124,7 +126,7 @@ void free_buf(DevBuf& b) {
     b.bytes = 0;
 }
 
-void free_runs(kmc_ctx* c);
+void free_runs(kmc_ctx* c, bool release);
 
 void free_table(Table& t) {
     if (t.hi) (void)hipFree(t.hi);
@@ -150,13 +152,47 @@ int alloc_table(kmc_ctx* c, Table& t, u64 cap) {
     return KMC_OK;
 }
 
-void free_runs(kmc_ctx* c) {
-    for (auto& r : c->runs) {
-        if (r.hi) (void)hipFree(r.hi);
-        if (r.lo) (void)hipFree(r.lo);
-        if (r.cnt) (void)hipFree(r.cnt);
-    }
+// drop the live runs; their buffers go back to the pool (release == true: really free everything)
+void free_runs(kmc_ctx* c, bool release = false) {
+    for (auto& r : c->runs) { r.n = 0; c->run_pool.push_back(r); }
     c->runs.clear();
+    if (release) {
+        for (auto& r : c->run_pool) {
+            if (r.hi) (void)hipFree(r.hi);
+            if (r.lo) (void)hipFree(r.lo);
+            if (r.cnt) (void)hipFree(r.cnt);
+        }
+        c->run_pool.clear();
+    }
+}
+
+// a run with room for `cap` entries: the smallest fitting pooled one, else a new allocation
+int take_run(kmc_ctx* c, u64 cap, kmc_ctx::Run* out) {
+    int best = -1;
+    for (size_t i = 0; i < c->run_pool.size(); ++i)
+        if (c->run_pool[i].cap >= cap && (best < 0 || c->run_pool[i].cap < c->run_pool[(size_t)best].cap)) best = (int)i;
+    if (best >= 0) {
+        *out = c->run_pool[(size_t)best];
+        c->run_pool.erase(c->run_pool.begin() + best);
+        out->n = 0;
+        return KMC_OK;
+    }
+    if (!c->run_pool.empty()) {  // nothing fits: recycle the memory of the largest pooled buffer
+        size_t big = 0;
+        for (size_t i = 1; i < c->run_pool.size(); ++i) if (c->run_pool[i].cap > c->run_pool[big].cap) big = i;
+        kmc_ctx::Run r = c->run_pool[big];
+        c->run_pool.erase(c->run_pool.begin() + (long)big);
+        if (r.hi) (void)hipFree(r.hi);
+        (void)hipFree(r.lo);
+        (void)hipFree(r.cnt);
+    }
+    kmc_ctx::Run r;
+    r.cap = cap + cap / 16 + 64;
+    HIPCHK(c, hipMalloc((void**)&r.lo, r.cap * sizeof(u64)));
+    if (hipMalloc((void**)&r.cnt, r.cap * sizeof(u64)) != hipSuccess) { (void)hipFree(r.lo); return fail(c, KMC_ERR_NOMEM, "out of device memory for a sorted run"); }
+    if (c->KW == 2 && hipMalloc((void**)&r.hi, r.cap * sizeof(u64)) != hipSuccess) { (void)hipFree(r.lo); (void)hipFree(r.cnt); return fail(c, KMC_ERR_NOMEM, "out of device memory for a sorted run"); }
+    *out = r;
+    return KMC_OK;
 }
 
 GTable gtable_of(const kmc_ctx* c, const Table& t) {
@@ -406,11 +442,10 @@ int collapse_runs(kmc_ctx* c, const u64* hi, const u64* lo, const u64* cnt_in, u
     const bool last_is_sentinel = drop_sentinel && (c->KW == 2 ? last_hi == ~0ull : last_lo == ~0ull);
     const u64 keep = n_runs - (last_is_sentinel ? 1 : 0);
     kmc_ctx::Run run;
+    rc = take_run(c, std::max<u64>(n_runs, 1), &run);
+    if (rc) return rc;
     run.n = keep;
-    HIPCHK(c, hipMalloc((void**)&run.lo, std::max<u64>(n_runs, 1) * sizeof(u64)));
-    HIPCHK(c, hipMalloc((void**)&run.cnt, std::max<u64>(n_runs, 1) * sizeof(u64)));
-    if (c->KW == 2) HIPCHK(c, hipMalloc((void**)&run.hi, std::max<u64>(n_runs, 1) * sizeof(u64)));
-    c->runs.push_back(run);  // owned from here on (freed by free_runs even if a later step fails)
+    c->runs.push_back(run);  // owned from here on (returned to the pool by free_runs even if a later step fails)
     rc = ensure(c, c->s_head, (size_t)(n_runs + 1) * sizeof(u64));
     if (rc) return rc;
     u64* head = (u64*)c->s_head.p;
@@ -424,12 +459,8 @@ int collapse_runs(kmc_ctx* c, const u64* hi, const u64* lo, const u64* cnt_in, u
     }
     HIPCHK(c, hipGetLastError());
     if (!keep) {  // nothing valid in this pass: drop the empty run again
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        kmc_ctx::Run r = c->runs.back();
+        c->run_pool.push_back(c->runs.back());
         c->runs.pop_back();
-        if (r.hi) (void)hipFree(r.hi);
-        (void)hipFree(r.lo);
-        (void)hipFree(r.cnt);
     }
     return KMC_OK;
 }
@@ -452,10 +483,10 @@ int sort_keys_buffers(kmc_ctx* c, u64 n, int* where) {
 }
 
 // Count the windows ending in [range_begin, n_bases) by extract -> sort -> run-length, in sub-batches
-// of at most 2^29 base positions (8-16 GiB of keys in flight).  Each sub-batch leaves one run.
+// of at most 2^31 base positions (2 x 16-32 GiB of keys in flight).  Each sub-batch leaves one run.
 int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 range_begin) {
     const u64 n_chunks = (n_bases + KMC_CHUNK - 1) / KMC_CHUNK;
-    const u64 SB = 1ull << 19;  // chunks per sub-batch
+    const u64 SB = 1ull << 21;  // chunks per sub-batch (2^31 positions: the run kernels index with u32)
     for (u64 cb = range_begin / KMC_CHUNK; cb < n_chunks; cb += SB) {
         const u64 ce = std::min(n_chunks, cb + SB);
         const u64 n = (ce - cb) * KMC_CHUNK;
@@ -697,7 +728,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
                       &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo,
                       &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->s_flags, &c->s_pos, &c->s_head};
-    free_runs(c);
+    free_runs(c, true);
     for (DevBuf* b : bufs) free_buf(*b);
     for (hipEvent_t e : c->lev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -772,7 +803,7 @@ extern "C" int kmc_reset(kmc_ctx* c) {
     c->pending = false;
     c->sorted_valid = false;
     c->n_sorted = 0;
-    free_runs(c);
+    free_runs(c, false);
     c->direct_seen = c->kmers_seen = 0;
     c->batch_pending = false;
     c->unpolled_adds = 0;
@@ -876,19 +907,37 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
     for (auto& r : c->runs) n_runs_total += r.n;
     u64 n = n_tab + n_runs_total;  // entries before merging duplicates across sources
     u64 n_kmers = 0;
-    const size_t nb = (size_t)std::max<u64>(n, 1) * sizeof(u64);
-    DevBuf* need[] = {&c->o_lo, &c->o_cnt, &c->t_lo, &c->t_cnt, &c->t_idx0, &c->t_idx1, &c->t_key};
-    for (DevBuf* b : need) { rc = ensure(c, *b, nb); if (rc) return rc; }
-    if (c->KW == 2) { rc = ensure(c, c->o_hi, nb); if (rc) return rc; rc = ensure(c, c->t_hi, nb); if (rc) return rc; }
     const bool single_run = n_tab == 0 && c->runs.size() == 1;
+    const bool lean_merge = !c->runs.empty() && c->KW == 1;  // merge by sorting (key, count) pairs directly
+    if (!single_run) {
+        if (!c->runs.empty()) {
+            // a merge of big runs needs room: give back the sort path's scratch and the pooled buffers
+            DevBuf* scratch[] = {&c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->s_head};
+            for (DevBuf* b : scratch) free_buf(*b);
+            for (auto& r : c->run_pool) { if (r.hi) (void)hipFree(r.hi); (void)hipFree(r.lo); (void)hipFree(r.cnt); }
+            c->run_pool.clear();
+        }
+        const size_t nb = (size_t)std::max<u64>(n, 1) * sizeof(u64);
+        DevBuf* need[] = {&c->o_lo, &c->o_cnt, &c->t_lo, &c->t_cnt};
+        for (DevBuf* b : need) { rc = ensure(c, *b, nb); if (rc) return rc; }
+        if (!lean_merge) {
+            DevBuf* need2[] = {&c->t_idx0, &c->t_idx1, &c->t_key};
+            for (DevBuf* b : need2) { rc = ensure(c, *b, nb); if (rc) return rc; }
+        } else if (n_tab) {
+            rc = ensure(c, c->t_idx0, (size_t)std::max<u64>(n_tab, 1) * sizeof(u64));  // the compaction kernel writes it
+            if (rc) return rc;
+        }
+        if (c->KW == 2) { rc = ensure(c, c->o_hi, nb); if (rc) return rc; rc = ensure(c, c->t_hi, nb); if (rc) return rc; }
+    }
+    c->v_hi = c->KW == 2 ? (const u64*)c->o_hi.p : nullptr;
+    c->v_lo = (const u64*)c->o_lo.p;
+    c->v_cnt = (const u64*)c->o_cnt.p;
     if (single_run) {
-        // one sorted run and an empty table: it IS the sorted view
+        // one sorted run and an empty table: it IS the sorted view (no copy)
         auto& r = c->runs[0];
-        HIPCHK(c, hipMemcpyAsync(c->o_lo.p, r.lo, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->o_cnt.p, r.cnt, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-        if (c->KW == 2) HIPCHK(c, hipMemcpyAsync(c->o_hi.p, r.hi, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        c->v_hi = r.hi; c->v_lo = r.lo; c->v_cnt = r.cnt;
         HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM2], 0, sizeof(u64), c->stream));
-        hipLaunchKernelGGL(kmc_sum_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, (const u64*)c->o_cnt.p, n, c->d_counters);
+        hipLaunchKernelGGL(kmc_sum_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, r.cnt, n, c->d_counters);
         HIPCHK(c, hipGetLastError());
         rc = poll(c);
         if (rc) return rc;
@@ -918,8 +967,12 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
                 if (c->KW == 2) HIPCHK(c, hipMemcpyAsync((u64*)c->t_hi.p + off, r.hi, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
                 off += r.n;
             }
-            hipLaunchKernelGGL(kmc_iota_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, (u64*)c->t_idx0.p, n);
-            rc = sort_view(c, n);
+            if (lean_merge) {
+                rc = sort_pairs_kv<u64, u64>(c, (const u64*)c->t_lo.p, (u64*)c->o_lo.p, (const u64*)c->t_cnt.p, (u64*)c->o_cnt.p, n, std::max(2u * (unsigned)c->klen, 1u));
+            } else {
+                hipLaunchKernelGGL(kmc_iota_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, (u64*)c->t_idx0.p, n);
+                rc = sort_view(c, n);
+            }
             if (rc) return rc;
             const size_t before = c->runs.size();
             rc = collapse_runs(c, c->KW == 2 ? (const u64*)c->o_hi.p : nullptr, (const u64*)c->o_lo.p, (const u64*)c->o_cnt.p, n, false);
@@ -935,9 +988,7 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
                 hipLaunchKernelGGL(kmc_sum_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, (const u64*)c->o_cnt.p, n, c->d_counters);
                 HIPCHK(c, hipGetLastError());
                 rc = poll(c);
-                if (m.hi) (void)hipFree(m.hi);
-                (void)hipFree(m.lo);
-                (void)hipFree(m.cnt);
+                c->run_pool.push_back(m);
                 if (rc) return rc;
                 n_kmers = c->h_counters[KMC_CTR_SUM2];
             } else {
@@ -975,10 +1026,10 @@ extern "C" int kmc_export(kmc_ctx* c, uint64_t* key_hi, uint64_t* key_lo, uint64
     if (!n) return KMC_OK;
     if (!key_lo || !count) return fail(c, KMC_ERR_ARG, "null buffer");
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    HIPCHK(c, hipMemcpyAsync(key_lo, c->o_lo.p, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(count, c->o_cnt.p, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(key_lo, c->v_lo, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(count, c->v_cnt, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     if (key_hi) {
-        if (c->KW == 2) HIPCHK(c, hipMemcpyAsync(key_hi, c->o_hi.p, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        if (c->KW == 2) HIPCHK(c, hipMemcpyAsync(key_hi, c->v_hi, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         else memset(key_hi, 0, n * sizeof(u64));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -988,9 +1039,9 @@ extern "C" int kmc_export(kmc_ctx* c, uint64_t* key_hi, uint64_t* key_lo, uint64
 extern "C" int kmc_export_device(kmc_ctx* c, const void** d_key_hi, const void** d_key_lo, const void** d_count, uint64_t* n_distinct) {
     if (!c) return KMC_ERR_ARG;
     if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_export_device before kmc_finalize");
-    if (d_key_hi) *d_key_hi = c->KW == 2 ? c->o_hi.p : nullptr;
-    if (d_key_lo) *d_key_lo = c->o_lo.p;
-    if (d_count) *d_count = c->o_cnt.p;
+    if (d_key_hi) *d_key_hi = c->KW == 2 ? c->v_hi : nullptr;
+    if (d_key_lo) *d_key_lo = c->v_lo;
+    if (d_count) *d_count = c->v_cnt;
     if (n_distinct) *n_distinct = c->n_sorted;
     return KMC_OK;
 }
@@ -1011,16 +1062,16 @@ extern "C" int kmc_partition_device(kmc_ctx* c, uint32_t n_parts, uint64_t* part
     std::vector<u64> owners((size_t)n);
     if (n) {
         int g2 = grid_for(c, n, 256);
-        hipLaunchKernelGGL(kmc_owner_kernel, dim3(g2), dim3(256), 0, c->stream, c->KW == 2 ? (const u64*)c->o_hi.p : (const u64*)nullptr,
-                           (const u64*)c->o_lo.p, n, n_parts, (u64*)c->t_key.p);
+        hipLaunchKernelGGL(kmc_owner_kernel, dim3(g2), dim3(256), 0, c->stream, c->KW == 2 ? c->v_hi : (const u64*)nullptr,
+                           c->v_lo, n, n_parts, (u64*)c->t_key.p);
         hipLaunchKernelGGL(kmc_iota_kernel, dim3(g2), dim3(256), 0, c->stream, (u64*)c->t_idx0.p, n);
         unsigned bits = 1;
         while ((1ull << bits) < n_parts) bits++;
         rc = sort_pairs<u64>(c, (const u64*)c->t_key.p, (u64*)c->t_lo.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, bits);
         if (rc) return rc;
-        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->o_lo.p, (const u64*)c->t_idx1.p, (u64*)c->p_lo.p, n);
-        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->o_cnt.p, (const u64*)c->t_idx1.p, (u64*)c->p_cnt.p, n);
-        if (c->KW == 2) hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->o_hi.p, (const u64*)c->t_idx1.p, (u64*)c->p_hi.p, n);
+        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, c->v_lo, (const u64*)c->t_idx1.p, (u64*)c->p_lo.p, n);
+        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, c->v_cnt, (const u64*)c->t_idx1.p, (u64*)c->p_cnt.p, n);
+        if (c->KW == 2) hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, c->v_hi, (const u64*)c->t_idx1.p, (u64*)c->p_hi.p, n);
         HIPCHK(c, hipGetLastError());
         HIPCHK(c, hipMemcpyAsync(owners.data(), c->t_lo.p, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
