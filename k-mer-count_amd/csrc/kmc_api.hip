@@ -82,7 +82,8 @@ struct kmc_ctx {
     bool timed = false;    // ev0/ev1 bracket a finished batch
     bool batch_pending = false;  // a COUNT kernel (unknown number of new keys) is queued since the last poll
     u64 unpolled_adds = 0;       // upper bound of keys added by merge kernels since the last poll
-    bool walk_overflowed = false;  // the last WALK batch counted >5% of its k-mers directly
+    bool walk_overflowed = false;  // the last WALK/STREAM launches counted >5% of their k-mers with global atomics
+                                   // (memo / LDS table overflow = high-cardinality input)
     u64 direct_seen = 0, kmers_seen = 0;
     bool pending = false;  // a batch has been queued since the last counter poll
     double rho_last = 0.0; // same, over the most recent sub-batch
@@ -237,7 +238,7 @@ int poll(kmc_ctx* c) {
         // share of k-mers the walk kernel had to count directly since the previous poll
         u64 d = c->h_counters[KMC_CTR_BADBASE], n = c->h_counters[KMC_CTR_KMERS];
         u64 dd = d - c->direct_seen, dn = n - c->kmers_seen;
-        if (d >= c->direct_seen && n > c->kmers_seen && c->st.algo_last == KMC_ALGO_WALK) c->walk_overflowed = dd * 20 > dn;
+        if (d >= c->direct_seen && n > c->kmers_seen && (c->st.algo_last == KMC_ALGO_WALK || c->st.algo_last == KMC_ALGO_STREAM)) c->walk_overflowed = dd * 20 > dn;
         c->direct_seen = d;
         c->kmers_seen = n;
     }
@@ -658,8 +659,9 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 if (done < n_chunks) {
                     rc = observe(occ, take, KMC_CHUNK);
                     if (rc) return rc;
-                    if (is_auto && c->rho_last > 0.2) {
-                        // more than one new key per five k-mers: per-occurrence hashing is the wrong tool
+                    if (is_auto && (c->rho_last > 0.2 || c->walk_overflowed)) {
+                        // many new keys per k-mer, or the LDS partial tables overflow and most k-mers go to
+                        // global atomics anyway: per-occurrence hashing is the wrong tool
                         stream_from = done * KMC_CHUNK;
                         run_sort = true;
                         c->prefer_sort = true;

@@ -38,7 +38,7 @@ template <int KW> struct StreamLds {
 // probe budget is exhausted or the table is (nearly) full.  Same wave-uniform loop shape as
 // gtable_add (see there for why).
 template <int KW>
-__device__ __forceinline__ void lds_add(StreamLds<KW>& L, const GTable& g, u64 hi, u64 lo, bool lds_ok) {
+__device__ __forceinline__ bool lds_add(StreamLds<KW>& L, const GTable& g, u64 hi, u64 lo, bool lds_ok) {
     constexpr u32 M = StreamLds<KW>::LCAP - 1;
     u32 h = kmc_hash32<KW>(hi, lo) & M;
     int probes = lds_ok ? 0 : 1000;
@@ -78,6 +78,7 @@ __device__ __forceinline__ void lds_add(StreamLds<KW>& L, const GTable& g, u64 h
         }
     }
     if (to_global) gtable_add<KW>(g, hi, lo, 1);
+    return to_global;  // counted with a global atomic instead of the LDS partial table
 }
 
 // wide bit masks for the validity smear: 64 bits cover the 48-base window of KW==1,
@@ -150,7 +151,7 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
     u64 c1 = c0 + chunks_per_wave;
     if (c1 > chunk_end) c1 = chunk_end;
 
-    u64 nk = 0;
+    u64 nk = 0, nglobal = 0;
     if (c0 < c1) {
         // uniform key masks
         const int kb = 2 * k;
@@ -288,7 +289,7 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         }
                         const bool ok = !((inv16 >> j) & 1);
                         if constexpr (SINK == 0) {
-                            if (ok) { lds_add<KW>(L, g, khi, klo, lds_ok); nk++; }
+                            if (ok) { nglobal += lds_add<KW>(L, g, khi, klo, lds_ok) ? 1u : 0u; nk++; }
                         } else {
                             o_lo[j] = ok ? klo : ~0ull;
                             if (KW == 2) o_hi[j] = ok ? khi : ~0ull;
@@ -302,7 +303,9 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
         }
     }
     nk = wave_sum_u64(nk);
+    nglobal = wave_sum_u64(nglobal);
     if (lane == 0 && nk) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_KMERS], nk);
+    if (lane == 0 && nglobal) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_BADBASE], nglobal);  // "direct" k-mers
 
     if constexpr (SINK == 0) {
         __syncthreads();
