@@ -54,6 +54,7 @@ struct kmc_ctx {
     Table tab;
     u64* d_counters = nullptr;      // KMC_CTR_N u64
     u64* h_counters = nullptr;      // pinned mirror
+    u64* occ_list = nullptr;        // first KMC_OCC_LIST_CAP claimed slots (fast finalize of small tables)
     u64 *spill_hi = nullptr, *spill_lo = nullptr, *spill_cnt = nullptr;
     u64 spill_cap = 0;
 
@@ -207,6 +208,8 @@ GTable gtable_of(const kmc_ctx* c, const Table& t) {
     g.spill_lo = c->spill_lo;
     g.spill_cnt = c->spill_cnt;
     g.spill_cap = c->spill_cap;
+    g.occ_list = c->occ_list;
+    g.occ_list_cap = c->occ_list ? KMC_OCC_LIST_CAP : 0;
     return g;
 }
 
@@ -724,6 +727,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     free_table(c->tab);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->occ_list) (void)hipFree(c->occ_list);
     if (c->spill_hi) (void)hipFree(c->spill_hi);
     if (c->spill_lo) (void)hipFree(c->spill_lo);
     if (c->spill_cnt) (void)hipFree(c->spill_cnt);
@@ -771,6 +775,7 @@ extern "C" int kmc_create(kmc_ctx** out, const kmc_config* cfg) {
         memset(c->h_counters, 0, KMC_CTR_N * sizeof(u64));
         u64 cap = next_pow2(std::max<u64>(cfg->capacity_hint * 2, 1ull << 20));
         c->spill_cap = std::max<u64>(cap / 4, 1ull << 18);
+        HIPCHK(c, hipMalloc((void**)&c->occ_list, KMC_OCC_LIST_CAP * sizeof(u64)));
         HIPCHK(c, hipMalloc((void**)&c->spill_lo, c->spill_cap * sizeof(u64)));
         HIPCHK(c, hipMalloc((void**)&c->spill_cnt, c->spill_cap * sizeof(u64)));
         if (c->KW == 2) HIPCHK(c, hipMalloc((void**)&c->spill_hi, c->spill_cap * sizeof(u64)));
@@ -934,7 +939,17 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
     c->v_hi = c->KW == 2 ? (const u64*)c->o_hi.p : nullptr;
     c->v_lo = (const u64*)c->o_lo.p;
     c->v_cnt = (const u64*)c->o_cnt.p;
-    if (single_run) {
+    if (c->runs.empty() && n_tab > 0 && n_tab <= KMC_OCC_LIST_CAP) {
+        // small table: one single-workgroup kernel gathers, sorts and writes the view
+        HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM2], 0, sizeof(u64), c->stream));
+        GTable g = gtable_of(c, c->tab);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(1), dim3(1024), 0, c->stream, g, n_tab, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+        else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(1), dim3(1024), 0, c->stream, g, n_tab, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+        HIPCHK(c, hipGetLastError());
+        rc = poll(c);
+        if (rc) return rc;
+        n_kmers = c->h_counters[KMC_CTR_SUM2];
+    } else if (single_run) {
         // one sorted run and an empty table: it IS the sorted view (no copy)
         auto& r = c->runs[0];
         c->v_hi = r.hi; c->v_lo = r.lo; c->v_cnt = r.cnt;

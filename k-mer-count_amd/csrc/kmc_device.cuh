@@ -35,7 +35,11 @@ struct GTable {
     u64* spill_lo;
     u64* spill_cnt;
     u64  spill_cap;
+    u64* occ_list;     // slot index of the i-th claimed slot, for i < occ_list_cap (small-table fast finalize)
+    u64  occ_list_cap;
 };
+
+#define KMC_OCC_LIST_CAP 8192
 
 __device__ __forceinline__ u64 kmc_mix64(u64 z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -104,7 +108,8 @@ __device__ __forceinline__ void gtable_add(const GTable& g, u64 hi, u64 lo, u64 
                 if (cur == KMC_EMPTY64) {
                     cur = atomicCAS((unsigned long long*)&g.key_lo[h], KMC_EMPTY64, lo);
                     if (cur == KMC_EMPTY64) {
-                        atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
+                        const u64 i = atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
+                        if (i < g.occ_list_cap) g.occ_list[i] = h;
                         cur = lo;
                     }
                 }
@@ -127,7 +132,8 @@ __device__ __forceinline__ void gtable_add(const GTable& g, u64 hi, u64 lo, u64 
                         __hip_atomic_store(&g.key_lo[h], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __hip_atomic_store(&g.key_hi[h], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
+                        const u64 i = atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
+                        if (i < g.occ_list_cap) g.occ_list[i] = h;
                         atomicAdd((unsigned long long*)&g.count[h], cnt);
                         done = true;
                     }

@@ -107,3 +107,60 @@ __global__ void kmc_sum_kernel(const u64* cnt, u64 n, u64* counters) {
     a = wave_sum_u64(a);
     if ((threadIdx.x & 63) == 0 && a) atomicAdd((unsigned long long*)&counters[KMC_CTR_SUM2], a);
 }
+
+// Fast finalize for small tables (n <= KMC_OCC_LIST_CAP claimed slots, listed in g.occ_list): ONE
+// workgroup gathers the keys, sorts them in LDS (bitonic network, ascending by (hi, lo)) and writes
+// the sorted view and the sum of counts -- instead of scanning the whole table, three library sort
+// launches and a gather.  This is the GPU form of the reference's final ordering step
+// (k-mer-count/src/main.rs:87) for the common case of a few thousand distinct keys.
+template <int KW>
+__global__ __launch_bounds__(1024)
+void kmc_small_finalize_kernel(GTable g, u64 n, u64* __restrict__ out_hi, u64* __restrict__ out_lo, u64* __restrict__ out_cnt) {
+    __shared__ u64 s_lo[KMC_OCC_LIST_CAP];
+    __shared__ u64 s_hi[KW == 2 ? KMC_OCC_LIST_CAP : 1];
+    __shared__ unsigned short s_ix[KMC_OCC_LIST_CAP];
+    const int tid = threadIdx.x;
+    u32 N = 1;
+    while (N < n) N <<= 1;  // padded to a power of two with all-ones keys (sort last)
+    for (u32 i = tid; i < N; i += 1024) {
+        if (i < n) {
+            const u64 slot = g.occ_list[i];
+            s_lo[i] = g.key_lo[slot];
+            if (KW == 2) s_hi[i] = g.key_hi[slot];
+        } else {
+            s_lo[i] = ~0ull;
+            if (KW == 2) s_hi[i] = ~0ull;
+        }
+        s_ix[i] = (unsigned short)i;
+    }
+    __syncthreads();
+    for (u32 kk = 2; kk <= N; kk <<= 1) {
+        for (u32 j = kk >> 1; j > 0; j >>= 1) {
+            for (u32 t = tid; t < N / 2; t += 1024) {
+                const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // lower element of the pair
+                const u32 p = i | j;
+                const bool up = (i & kk) == 0;
+                const u64 alo = s_lo[i], blo = s_lo[p];
+                bool gt;
+                if (KW == 2) { const u64 ahi = s_hi[i], bhi = s_hi[p]; gt = ahi > bhi || (ahi == bhi && alo > blo); }
+                else gt = alo > blo;
+                if (gt == up) {
+                    s_lo[i] = blo; s_lo[p] = alo;
+                    if (KW == 2) { const u64 th = s_hi[i]; s_hi[i] = s_hi[p]; s_hi[p] = th; }
+                    const unsigned short tx = s_ix[i]; s_ix[i] = s_ix[p]; s_ix[p] = tx;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    u64 sum = 0;
+    for (u32 i = tid; i < n; i += 1024) {
+        const u64 c = g.count[g.occ_list[s_ix[i]]];
+        out_lo[i] = s_lo[i];
+        if (KW == 2) out_hi[i] = s_hi[i];
+        out_cnt[i] = c;
+        sum += c;
+    }
+    sum = wave_sum_u64(sum);
+    if ((tid & 63) == 0 && sum) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_SUM2], sum);
+}

@@ -315,11 +315,16 @@ __device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s,
 }
 
 // 16 ASCII bases -> one 32-bit word, 2 bits per base, first base in the low bits, internal code
-// A0 C1 T2 G3 = (byte>>1)&3 (no G/T fix-up on the hot path; walk_roll converts).  xany != 0 iff a
-// byte is not one of "ACGT" (v_perm_b32 as an 8-entry LUT: selectors 4..7 read 0x00).
+// A0 C1 T2 G3 = (byte>>1)&3 (no G/T fix-up on the hot path; walk_roll converts).  A byte is one of
+// "ACGT" iff it equals LUT[(byte>>1)&3] (v_perm_b32 as a 4-entry byte LUT), so x != 0 marks exactly
+// the other bytes.  The selector MUST be masked to 2 bits before the words are combined: bytes past
+// the end of the batch are arbitrary, and a third selector bit would spill into a neighbouring --
+// valid -- base when the fields are interleaved below (seen as a one-in-10^4 single-base
+// corruption in the last piece of a batch on boxes whose fresh memory held garbage;
+// tests/test_gpu_parity.py::test_garbage_after_the_batch_is_ignored).
 __device__ __forceinline__ u32 walk_encode16(uint4 v, u32& x0, u32& x1, u32& x2, u32& x3) {
-    const u32 s0 = (v.x >> 1) & 0x07070707u, s1 = (v.y >> 1) & 0x07070707u;
-    const u32 s2 = (v.z >> 1) & 0x07070707u, s3 = (v.w >> 1) & 0x07070707u;
+    const u32 s0 = (v.x >> 1) & 0x03030303u, s1 = (v.y >> 1) & 0x03030303u;
+    const u32 s2 = (v.z >> 1) & 0x03030303u, s3 = (v.w >> 1) & 0x03030303u;
     x0 = v.x ^ __builtin_amdgcn_perm(0u, 0x47544341u, s0);
     x1 = v.y ^ __builtin_amdgcn_perm(0u, 0x47544341u, s1);
     x2 = v.z ^ __builtin_amdgcn_perm(0u, 0x47544341u, s2);

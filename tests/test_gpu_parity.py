@@ -389,3 +389,28 @@ def test_walk_repeatability_stress(kmc, oracle):
         for algo in (kmc.ALGO_WALK, kmc.ALGO_STREAM, kmc.ALGO_WALK):
             t, _ = _count(kmc, bases, offs, k, True, algo)
             assert t.equals(want), (it, k, algo)
+
+
+def test_garbage_after_the_batch_is_ignored(kmc, oracle):
+    """Device-resident batches whose last 16-byte piece is followed by arbitrary bytes (the ABI only
+    promises readability up to the next 16-byte boundary).  Regression test: a 3-bit LUT selector
+    in the walk kernel's encoder let such bytes corrupt valid bases 1..4 of the last piece."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(99)
+    for tail_fill in (0xFF, 0x7E, 0x0D, 0x5C, 0x00):
+        for n_extra in (1, 5, 8, 13):
+            lens = np.full(257, 150)
+            lens[-1] = 150 + n_extra                  # make n_bases % 16 vary
+            offs = np.zeros(258, np.uint64)
+            offs[1:] = np.cumsum(lens)
+            n = int(offs[-1])
+            bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+            d_b = torch.full((n + 256,), tail_fill, dtype=torch.uint8, device="cuda")
+            d_b[:n] = torch.from_numpy(bases).cuda()
+            d_o = torch.from_numpy(offs.astype(np.int64)).cuda()
+            for k in (21, 47):
+                want = oracle.count_kmers(bases, offs, k, True)
+                for algo in (kmc.ALGO_WALK, kmc.ALGO_STREAM, kmc.ALGO_SORT):
+                    with kmc.KmerCounter(k=k, algo=algo) as kc:
+                        kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), 257, n, int(lens.max()))
+                        assert kc.export().equals(want), (hex(tail_fill), n_extra, k, algo)
