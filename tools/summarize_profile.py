@@ -12,21 +12,29 @@ src, dst, kname, bases, k, algo = sys.argv[1], sys.argv[2], sys.argv[3], int(sys
 os.makedirs(os.path.dirname(dst), exist_ok=True)
 stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 shutil.copy(stats, dst + "_kernel_stats.csv")
-avg_ns = None
-for r in csv.DictReader(open(stats)):
-    if kname in r["Name"]:
-        avg_ns = float(r["AverageNs"]); calls = int(r["Calls"])
+# The first step of a fresh context ramps up through a few small launches; only the
+# full-batch launches (duration >= 80 % of the longest) are averaged below.  The raw --stats file
+# (all launches) is kept next to this summary.
+trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
+durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(trace)) if kname in r["Kernel_Name"]]
+full = [d for d in durs if d >= 0.8 * max(durs)]
+full = full[-5:]  # the timed steps (the warm-up steps before them run at a lower clock)
+avg_ns = sum(full) / len(full); calls = len(full)
 ctr = collections.defaultdict(list)
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.csv"))):
-    for r in csv.DictReader(open(f)):
-        if kname in r["Kernel_Name"]:
+    rows = [r for r in csv.DictReader(open(f)) if kname in r["Kernel_Name"]]
+    if not rows:
+        continue
+    dmax = max(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in rows)
+    for r in rows:
+        if float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) >= 0.8 * dmax:
             ctr[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {c: sum(v) / len(v) for c, v in ctr.items()}
 # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
 # half of the bytes of a wide coalesced streaming read (16 B/lane) -> double it; WRITE_SIZE exact.
 fetch = avg.get("FETCH_SIZE", 0) * 1024 * 2
 write = avg.get("WRITE_SIZE", 0) * 1024
-out = {"kernel": kname, "calls_traced": calls, "avg_duration_ns": avg_ns, "counters_avg_per_launch": avg,
+out = {"kernel": kname, "full_batch_launches_traced": calls, "all_launches_traced": len(durs), "avg_duration_ns": avg_ns, "counters_avg_per_launch": avg,
        "hbm_read_bytes_per_launch": fetch, "hbm_write_bytes_per_launch": write,
        "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for 16 B/lane streams); separate --pmc passes"}
 json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
