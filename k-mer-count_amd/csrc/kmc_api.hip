@@ -620,13 +620,18 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             while (done < n_tiles) {
                 u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
                 u64 take = plan(n_tiles - done, kpt, prev);
-                rc = launch_begin(c);
+                rc = kmc_walk_prepare(c->stream, c->walk_ws.p);
+                if (rc) return fail(c, rc, "walk workspace reset failed");
+                rc = launch_begin(c);  // the event pair brackets the walk kernel alone
                 if (rc) return rc;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_offsets, n_reads, n_bases,
-                                     done, done + take, c->walk_ws.p, c->walk_memo.p, gtable_of(c, c->tab));
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, gtable_of(c, c->tab), 0);
                 if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
                 rc = launch_end(c);
                 if (rc) return rc;
+                rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_offsets, n_reads, n_bases,
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, gtable_of(c, c->tab), 1);
+                if (rc) return fail(c, rc, "scalar kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
                 c->pending = true;
                 done += take;
                 prev = take;

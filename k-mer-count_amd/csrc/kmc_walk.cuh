@@ -594,30 +594,36 @@ static inline size_t kmc_walk_workspace_bytes(u64 n_reads) { return sizeof(WalkW
 
 template <int KW, bool CANON>
 static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const uint8_t* d_bases, const u64* d_offsets,
-                                     u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, void* memo, GTable g) {
+                                     u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, void* memo, GTable g, int phase) {
     const size_t smem = sizeof(WalkLds<KW>);
     static bool attr = false;  // one flag per instantiation
     if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<KW, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-    hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, tile_begin, tile_end, hdr, list, (WalkMemoSlot<KW>*)memo, g);
-    hipLaunchKernelGGL((kmc_scalar_reads_kernel<KW, CANON>), dim3(n_cu), dim3(256), 0, st, d_bases, d_offsets, hdr, list, k, g);
+    if (phase == 0)
+        hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, tile_begin, tile_end, hdr, list, (WalkMemoSlot<KW>*)memo, g);
+    else
+        hipLaunchKernelGGL((kmc_scalar_reads_kernel<KW, CANON>), dim3(n_cu), dim3(256), 0, st, d_bases, d_offsets, hdr, list, k, g);
 }
 
+// phase 0: the walk kernel over tiles [tile_begin, tile_end); phase 1: the scalar kernel for the reads
+// it diverted.  The caller clears the workspace header (kmc_walk_prepare) before phase 0.
+static inline int kmc_walk_prepare(hipStream_t st, void* ws) {
+    return hipMemsetAsync(ws, 0, sizeof(WalkWs), st) == hipSuccess ? KMC_OK : KMC_ERR_HIP;
+}
 static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool canon, const uint8_t* d_bases,
-                                  const u64* d_offsets, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, GTable g) {
+                                  const u64* d_offsets, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, GTable g, int phase) {
     if (n_reads >= (1ull << 32) || tile_end <= tile_begin) return KMC_ERR_ARG;
     WalkWs* hdr = (WalkWs*)ws;
     u32* list = (u32*)((char*)ws + sizeof(WalkWs));
-    if (hipMemsetAsync(hdr, 0, sizeof(WalkWs), st) != hipSuccess) return KMC_ERR_HIP;
     const u64 n_tiles = tile_end - tile_begin;
     u64 want = (n_tiles + KMC_WALK_WAVES - 1) / KMC_WALK_WAVES;
     int grid = (int)(want < (u64)n_cu ? want : (u64)n_cu);  // one 160 KB workgroup per CU is resident
     if (grid < 1) grid = 1;
     if (KW == 1) {
-        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g);
-        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g);
+        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g, phase);
+        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g, phase);
     } else {
-        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g);
-        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g);
+        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g, phase);
+        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g, phase);
     }
     return hipGetLastError() == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
