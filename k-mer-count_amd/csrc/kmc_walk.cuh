@@ -519,22 +519,45 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     }
 
     // ---- flush: unfold every memoised edge into its k-mers ----
+    // Work item = (edge, step): the k-mer completed by the step-th base of an edge's label.  First
+    // the used entries are compacted into a list (in wave 0's staging area, free by now), then the
+    // items are spread over all 1024 threads: ~4 independent global adds per thread instead of 16-32
+    // dependent ones on the few threads that happened to own a used entry (measured: 140 us -> the
+    // flush used to be 8 % of the whole kernel).
+    __syncthreads();
+    unsigned short* flist = reinterpret_cast<unsigned short*>(L.stage[0]);  // up to NCAP + ECAP entry indices
+    u32* fcount = &L.badbits[0][0];
+    if (tid == 0) *fcount = 0;
     __syncthreads();
     for (int i = tid; i < KMC_WALK_NCAP + KMC_WALK_ECAP; i += KMC_WALK_THREADS) {
+        u32 cnt;
+        if (i < KMC_WALK_NCAP) cnt = ((L.node[i].prim >> 32) != 0) ? L.node[i].cnt : 0;
+        else cnt = (L.edge[i - KMC_WALK_NCAP].kv != ~0ull) ? L.edge[i - KMC_WALK_NCAP].cnt : 0;
+        if (cnt) flist[atomicAdd(fcount, 1u)] = (unsigned short)i;
+    }
+    __syncthreads();
+    const u32 n_items = *fcount * KMC_WALK_STRIDE;
+    // every workgroup holds nearly the same entries in nearly the same order (slot = hash of the
+    // key): start each one at a different place so that they do not all hit one address at a time
+    const u32 rot = n_items ? (u32)(((u64)blockIdx.x * 2654435761u) % n_items) : 0;
+    for (u32 w0 = tid; w0 < n_items; w0 += KMC_WALK_THREADS) {
+        u32 w = w0 + rot;
+        if (w >= n_items) w -= n_items;
+        const u32 i = flist[w / KMC_WALK_STRIDE], step = w % KMC_WALK_STRIDE;
         u32 label, len, id, cnt;
         if (i < KMC_WALK_NCAP) {
-            id = (u32)i; label = (u32)L.node[i].prim; len = KMC_WALK_STRIDE;
-            cnt = ((L.node[i].prim >> 32) != 0) ? L.node[i].cnt : 0;
+            id = i; label = (u32)L.node[i].prim; len = KMC_WALK_STRIDE; cnt = L.node[i].cnt;
         } else {
             const u64 kv = L.edge[i - KMC_WALK_NCAP].kv;
-            cnt = (kv != ~0ull) ? L.edge[i - KMC_WALK_NCAP].cnt : 0;
+            cnt = L.edge[i - KMC_WALK_NCAP].cnt;
             label = (u32)kv; len = ((u32)(kv >> 32) & 15u) + 1; id = (u32)(kv >> 36) & (KMC_WALK_NCAP - 1);
         }
-        if (cnt) {
+        if (step < len) {
             WCtx ctx;
             u32 depth;
             node_decode<KW>(node_key_load<KW>(L, id), k, ctx, depth);
-            (void)walk_roll<KW, CANON, true>(g, ctx, depth, label, (int)len, k, mask_hi, mask_lo, cnt);
+            (void)walk_roll<KW, CANON, false>(g, ctx, depth, label, (int)step + 1, k, mask_hi, mask_lo, 0);  // context after base `step`
+            if (depth >= (u32)k) walk_gadd<KW, CANON>(g, ctx, k, cnt);
         }
     }
     // ---- save the memo (structure only) for the next launch ----
