@@ -1,0 +1,98 @@
+"""Property tests (hypothesis) of the CPU oracle and the host logic of libkmc -- no GPU needed."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+ALPH = b"ACGTNacgt-"
+
+
+@st.composite
+def read_sets(draw):
+    n = draw(st.integers(0, 12))
+    reads = [draw(st.binary(min_size=0, max_size=90).map(lambda b: bytes(ALPH[x % len(ALPH)] for x in b))) for _ in range(n)]
+    return reads
+
+
+def _pack(reads):
+    bases = np.frombuffer(b"".join(reads), np.uint8)
+    offs = np.cumsum([0] + [len(r) for r in reads]).astype(np.uint64)
+    return bases, offs
+
+
+def _naive(reads, k, canonical):
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    out = {}
+    for r in reads:
+        for i in range(len(r) - k + 1):
+            w = r[i:i + k]
+            if any(c not in b"ACGT" for c in w):
+                continue
+            if canonical:
+                rc = bytes(comp[c] for c in reversed(w))
+                w = min(w, rc)
+            out[w] = out.get(w, 0) + 1
+    return out
+
+
+@settings(max_examples=120, deadline=None)
+@given(read_sets(), st.integers(1, 40), st.booleans())
+def test_oracle_equals_naive_definition(oracle, reads, k, canonical):
+    """The oracle's three methods against a direct transcription of SURVEY.md 8a-def."""
+    bases, offs = _pack(reads)
+    want = _naive(reads, k, canonical)
+    for t in (oracle.count_kmers(bases, offs, k, canonical, 0), oracle.count_kmers(bases, offs, k, canonical, 1),
+              oracle.count_kmers_strings(bases, offs, k, canonical)):
+        got = {km.tobytes(): int(c) for km, c in zip(t.kmers(), t.count)}
+        assert got == want
+        keys = [km.tobytes() for km in t.kmers()]
+        assert keys == sorted(keys)                       # main.rs:87 order
+        assert t.n_total == sum(want.values())
+
+
+@settings(max_examples=60, deadline=None)
+@given(read_sets(), read_sets(), st.integers(1, 33))
+def test_counting_is_additive_over_record_shards(oracle, a, b, k):
+    """Records are independent units (main.rs:58-62,73-75): table(a + b) == table(a) + table(b)."""
+    ta = oracle.count_kmers(*_pack(a), k, True)
+    tb = oracle.count_kmers(*_pack(b), k, True)
+    tab = oracle.count_kmers(*_pack(a + b), k, True)
+    merged = {}
+    for t in (ta, tb):
+        for h, l, c in zip(t.key_hi, t.key_lo, t.count):
+            merged[(int(h), int(l))] = merged.get((int(h), int(l)), 0) + int(c)
+    assert merged == {(int(h), int(l)): int(c) for h, l, c in zip(tab.key_hi, tab.key_lo, tab.count)}
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.lists(st.tuples(st.binary(min_size=0, max_size=20), st.lists(st.binary(min_size=0, max_size=30), max_size=4)), max_size=6),
+       st.sampled_from([b"\n", b"\r\n"]), st.booleans())
+def test_host_reader_equals_oracle_reader(kmc, oracle, tmp_path_factory, records, eol, final_eol):
+    """Random FASTA text: the product's (multi-threaded) reader and the oracle's restatement agree."""
+    clean = lambda b: bytes(c for c in b if c not in b">\r\n")
+    text = b""
+    for hdr, lines in records:
+        text += b">" + clean(hdr) + eol + b"".join(clean(l) + eol for l in lines)
+    if not final_eol and text.endswith(eol):
+        text = text[:-len(eol)]
+    p = tmp_path_factory.mktemp("fa") / "x.fasta"
+    p.write_bytes(text)
+    try:
+        b2, o2 = oracle.parse_fasta(str(p))
+    except oracle.OracleError as e:
+        try:
+            kmc.parse_fasta(str(p))
+            assert False, "product accepted what the oracle rejects"
+        except kmc.KmcError as e2:
+            assert (e.code, e2.status) in ((-2, kmc.ERR_FORMAT), (-1, kmc.ERR_IO))
+        return
+    b1, o1 = kmc.parse_fasta(str(p))
+    assert np.array_equal(o1, o2) and np.array_equal(b1, b2)
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 2**62), st.integers(0, 10**7), st.integers(1, 300))
+def test_synth_ranges_are_consistent(kmc, seed, first, n):
+    s = kmc.Synth(seed=seed)
+    b, o = kmc.synth_reads_host(s, first, n)
+    b2, _ = kmc.synth_reads_host(s, first + n // 2, n - n // 2)
+    assert np.array_equal(b[(n // 2) * 400:], b2)
+    assert len(np.unique(b.reshape(-1, 80), axis=0)) <= 10
