@@ -53,17 +53,14 @@ __device__ __forceinline__ u64 kmc_hash_key(u64 hi, u64 lo) {
     return kmc_mix64(lo);
 }
 
-// Cheap 32-bit slot hash for the LDS tables (two v_mul_lo_u32 + a few xors).
+// 32-bit slot hash for the LDS tables: the high half of a 64-bit multiplicative mix (the low bits
+// of a plain 32-bit multiply cluster consecutive k-mers, which lengthens linear-probe chains).
 template <int KW>
 __device__ __forceinline__ u32 kmc_hash32(u64 hi, u64 lo) {
-    u32 a = (u32)lo, b = (u32)(lo >> 32);
-    u32 h = a * 0x9E3779B1u ^ b * 0x85EBCA77u;
-    if (KW == 2) {
-        u32 c = (u32)hi, d = (u32)(hi >> 32);
-        h ^= c * 0xC2B2AE3Du ^ d * 0x27D4EB2Fu;
-    }
-    h ^= h >> 15;
-    return h;
+    u64 z = lo;
+    if (KW == 2) z ^= hi * 0xC2B2AE3D27D4EB4Full;
+    z = (z ^ (z >> 29)) * 0x9E3779B97F4A7C15ull;
+    return (u32)(z >> 32) ^ (u32)(z >> 17);
 }
 
 __device__ __forceinline__ u64 ld_relaxed(const u64* p) {
