@@ -66,7 +66,8 @@ struct kmc_ctx {
     bool sorted_valid = false;
     // walk-kernel workspace
     DevBuf walk_ws;
-    DevBuf walk_memo;
+    DevBuf walk_memo;  // two shared memo snapshots + dense counters, kept across launches (kmc_walk.cuh)
+    int memo_parity = 0;  // snapshot slot the next walk launch reads
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
     DevBuf s_lo[2], s_hi[2], s_flags, s_pos, s_head;
     struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0, cap = 0; };
@@ -612,6 +613,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 rc = ensure(c, c->walk_memo, kmc_walk_memo_bytes(c->n_cu, c->KW));
                 if (rc) return rc;
                 HIPCHK(c, hipMemsetAsync(c->walk_memo.p, 0, kmc_walk_memo_bytes(c->n_cu, c->KW), c->stream));
+                c->memo_parity = 0;
                 c->walk_overflowed = false;
             }
             const u64 n_tiles = (n_reads + 63) / 64;
@@ -625,13 +627,14 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 rc = launch_begin(c);  // the event pair brackets the walk kernel alone
                 if (rc) return rc;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_offsets, n_reads, n_bases,
-                                     done, done + take, c->walk_ws.p, c->walk_memo.p, gtable_of(c, c->tab), 0);
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), 0);
                 if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
                 rc = launch_end(c);
                 if (rc) return rc;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_offsets, n_reads, n_bases,
-                                     done, done + take, c->walk_ws.p, c->walk_memo.p, gtable_of(c, c->tab), 1);
-                if (rc) return fail(c, rc, "scalar kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), 1);
+                if (rc) return fail(c, rc, "scalar/unfold kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+                c->memo_parity ^= 1;
                 c->pending = true;
                 done += take;
                 prev = take;

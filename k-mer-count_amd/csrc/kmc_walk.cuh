@@ -71,15 +71,23 @@ struct WalkLds {
     u32 nedges, nnodes;
 };
 
-// workspace header (device): [0] number of deferred reads; the u32 read indices follow at +64 B
+// workspace (device): [WalkWs header | gcnt[NCAP+ECAP] dense snapshot counters | u32 deferred read
+// indices]; one memset before every launch clears the header and the counters
 struct WalkWs {
     unsigned long long n_deferred;
     unsigned long long pad[7];
 };
+#define KMC_WALK_WS_PREFIX (sizeof(WalkWs) + (size_t)(KMC_WALK_NCAP + KMC_WALK_ECAP) * sizeof(u64))
 
 // The memo (nodes, node keys, edges -- no counters) is input-independent graph structure, so it is
-// kept across launches: every workgroup saves its tables to its slot at the end of a launch and
-// starts the next launch from them, which removes the per-launch warm-up of the slow path.
+// kept across launches as ONE shared snapshot: workgroup 0 saves its tables at the end of a launch
+// and EVERY workgroup of the next launch starts from that snapshot.  That removes the warm-up of the
+// slow path, and -- because all workgroups then agree on the slot of every snapshot entry -- lets
+// them reduce their per-slot traversal counters with dense, coalesced atomics into one small global
+// array (gcnt) that kmc_walk_unfold_kernel turns into k-mer counts ONCE, instead of every
+// workgroup scattering ~4 k global adds for the same k-mers (the flush was 70 us of a 1.7 ms launch).
+// Entries a workgroup discovers during the launch are not in the snapshot and take the scattered
+// path.  Two snapshot slots alternate (read A / write B) so that nothing reads a slot being written.
 template <int KW>
 struct WalkMemoSlot {
     u64 tag;  // KMC_WALK_MEMO_TAG | k when valid
@@ -341,7 +349,8 @@ __device__ __forceinline__ u32 walk_encode16(uint4 v, u32& x0, u32& x1, u32& x2,
 template <int KW, bool CANON>
 __global__ __launch_bounds__(KMC_WALK_THREADS)
 void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets, u64 n_reads,
-                     int k, u64 tile_begin, u64 tile_end, WalkWs* ws, u32* deferred, WalkMemoSlot<KW>* memo_slots, GTable g) {
+                     int k, u64 tile_begin, u64 tile_end, WalkWs* ws, u32* deferred, const WalkMemoSlot<KW>* memo,
+                     WalkMemoSlot<KW>* memo_out, u64* gcnt, GTable g) {
     extern __shared__ __align__(16) unsigned char walk_smem[];
     WalkLds<KW>& L = *reinterpret_cast<WalkLds<KW>*>(walk_smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -349,7 +358,6 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
 
-    WalkMemoSlot<KW>* memo = memo_slots ? &memo_slots[blockIdx.x] : nullptr;
     const bool warm = memo && memo->tag == (KMC_WALK_MEMO_TAG | (u64)k);  // workgroup-uniform
     for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) { L.edge[i].kv = warm ? memo->ekv[i] : ~0ull; L.edge[i].cnt = 0; }
     for (int i = tid; i < KMC_WALK_NCAP; i += KMC_WALK_THREADS) {
@@ -370,7 +378,9 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     u32* stage = L.stage[wv];
     u64 nk = 0, ndirect = 0;
     const u64 n_tiles = tile_end;  // this launch covers tiles [tile_begin, tile_end) of 64 reads
-    const u64 gw = tile_begin + (u64)blockIdx.x * KMC_WALK_WAVES + wv;
+    // wave ids interleave the workgroups (wave wv of every workgroup before wave wv+1 of any), so the
+    // last, partial round of tiles is spread over all CUs instead of filling the first third of them
+    const u64 gw = tile_begin + (u64)wv * gridDim.x + blockIdx.x;
     const u64 total_waves = (u64)gridDim.x * KMC_WALK_WAVES;
 
     // Per-tile geometry: the wave's 64 reads are the byte range [A, B) of the batch.
@@ -531,9 +541,18 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     __syncthreads();
     for (int i = tid; i < KMC_WALK_NCAP + KMC_WALK_ECAP; i += KMC_WALK_THREADS) {
         u32 cnt;
-        if (i < KMC_WALK_NCAP) cnt = ((L.node[i].prim >> 32) != 0) ? L.node[i].cnt : 0;
-        else cnt = (L.edge[i - KMC_WALK_NCAP].kv != ~0ull) ? L.edge[i - KMC_WALK_NCAP].cnt : 0;
-        if (cnt) flist[atomicAdd(fcount, 1u)] = (unsigned short)i;
+        bool snap;  // the entry came with the shared snapshot (it cannot have changed since: set-once fields)
+        if (i < KMC_WALK_NCAP) {
+            cnt = ((L.node[i].prim >> 32) != 0) ? L.node[i].cnt : 0;
+            snap = warm && (memo->prim[i] >> 32) != 0;
+        } else {
+            cnt = (L.edge[i - KMC_WALK_NCAP].kv != ~0ull) ? L.edge[i - KMC_WALK_NCAP].cnt : 0;
+            snap = warm && memo->ekv[i - KMC_WALK_NCAP] != ~0ull;
+        }
+        if (cnt) {
+            if (snap) atomicAdd((unsigned long long*)&gcnt[i], (unsigned long long)cnt);  // dense: slot i of every workgroup
+            else flist[atomicAdd(fcount, 1u)] = (unsigned short)i;
+        }
     }
     __syncthreads();
     const u32 n_items = *fcount * KMC_WALK_STRIDE;
@@ -561,14 +580,47 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         }
     }
     // ---- save the memo (structure only) for the next launch ----
-    if (memo) {
-        for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) memo->ekv[i] = L.edge[i].kv;
+    if (memo_out && blockIdx.x == 0) {
+        for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) memo_out->ekv[i] = L.edge[i].kv;
         for (int i = tid; i < KMC_WALK_NCAP; i += KMC_WALK_THREADS) {
-            memo->nkeys[i] = L.nkeys[i];
-            if (KW == 2) memo->nkeys_hi[i] = L.nkeys_hi[i];
-            memo->prim[i] = L.node[i].prim;
+            memo_out->nkeys[i] = L.nkeys[i];
+            if (KW == 2) memo_out->nkeys_hi[i] = L.nkeys_hi[i];
+            memo_out->prim[i] = L.node[i].prim;
         }
-        if (tid == 0) { memo->nedges = L.nedges; memo->nnodes = L.nnodes; memo->tag = KMC_WALK_MEMO_TAG | (u64)k; }
+        if (tid == 0) { memo_out->nedges = L.nedges; memo_out->nnodes = L.nnodes; memo_out->tag = KMC_WALK_MEMO_TAG | (u64)k; }
+    }
+}
+
+// Turns the traversal counters that all workgroups reduced into gcnt (one per snapshot slot) into
+// k-mer counts, once per launch (gcnt is cleared by kmc_walk_prepare before the next launch).
+template <int KW, bool CANON>
+__global__ __launch_bounds__(256)
+void kmc_walk_unfold_kernel(const WalkMemoSlot<KW>* memo, const u64* gcnt, int k, GTable g) {
+    if (memo->tag != (KMC_WALK_MEMO_TAG | (u64)k)) return;  // the launch ran without a snapshot: gcnt untouched
+    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    const int kb = 2 * k;
+    const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
+    const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
+    for (u32 w = tid; w < (KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE; w += nthreads) {
+        const u32 i = w / KMC_WALK_STRIDE, step = w % KMC_WALK_STRIDE;
+        const u64 cnt = gcnt[i];
+        if (!cnt) continue;
+        u32 label, len, id;
+        if (i < KMC_WALK_NCAP) {
+            id = i; label = (u32)memo->prim[i]; len = KMC_WALK_STRIDE;
+        } else {
+            const u64 kv = memo->ekv[i - KMC_WALK_NCAP];
+            label = (u32)kv; len = ((u32)(kv >> 32) & 15u) + 1; id = (u32)(kv >> 36) & (KMC_WALK_NCAP - 1);
+        }
+        if (step < len) {
+            WCtx nk, ctx;
+            nk.lo = memo->nkeys[id];
+            nk.hi = KW == 2 ? memo->nkeys_hi[id] : 0ull;
+            u32 depth;
+            node_decode<KW>(nk, k, ctx, depth);
+            (void)walk_roll<KW, CANON, false>(g, ctx, depth, label, (int)step + 1, k, mask_hi, mask_lo, 0);
+            if (depth >= (u32)k) walk_gadd<KW, CANON>(g, ctx, k, cnt);
+        }
     }
 }
 
@@ -612,41 +664,50 @@ __global__ void kmc_scalar_reads_kernel(const uint8_t* __restrict__ bases, const
 static inline bool kmc_walk_supported(int k, int mode, u64 max_read_len) {
     return mode == KMC_MODE_CONTIG && k >= 1 && k <= KMC_WALK_MAX_K && max_read_len >= 1 && max_read_len <= KMC_WALK_MAX_READ;
 }
-static inline size_t kmc_walk_memo_bytes(int n_cu, int KW) { return (size_t)n_cu * (KW == 1 ? sizeof(WalkMemoSlot<1>) : sizeof(WalkMemoSlot<2>)); }
-static inline size_t kmc_walk_workspace_bytes(u64 n_reads) { return sizeof(WalkWs) + (size_t)(n_reads + 16) * sizeof(u32); }
+// memo buffer: two snapshot slots + the dense counter array
+static inline size_t kmc_walk_slot_bytes(int KW) { return KW == 1 ? sizeof(WalkMemoSlot<1>) : sizeof(WalkMemoSlot<2>); }
+static inline size_t kmc_walk_memo_bytes(int, int KW) { return 2 * kmc_walk_slot_bytes(KW); }
+static inline size_t kmc_walk_workspace_bytes(u64 n_reads) { return KMC_WALK_WS_PREFIX + (size_t)(n_reads + 16) * sizeof(u32); }
 
 template <int KW, bool CANON>
 static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const uint8_t* d_bases, const u64* d_offsets,
-                                     u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, void* memo, GTable g, int phase) {
+                                     u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, u64* gcnt, void* memo, int parity, GTable g, int phase) {
     const size_t smem = sizeof(WalkLds<KW>);
     static bool attr = false;  // one flag per instantiation
     if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<KW, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
-    if (phase == 0)
-        hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, tile_begin, tile_end, hdr, list, (WalkMemoSlot<KW>*)memo, g);
-    else
+    WalkMemoSlot<KW>* slots = (WalkMemoSlot<KW>*)memo;
+    if (phase == 0) {
+        hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, tile_begin, tile_end, hdr, list,
+                           (const WalkMemoSlot<KW>*)&slots[parity], &slots[parity ^ 1], gcnt, g);
+    } else {
         hipLaunchKernelGGL((kmc_scalar_reads_kernel<KW, CANON>), dim3(n_cu), dim3(256), 0, st, d_bases, d_offsets, hdr, list, k, g);
+        hipLaunchKernelGGL((kmc_walk_unfold_kernel<KW, CANON>), dim3((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE / 256), dim3(256), 0, st,
+                           (const WalkMemoSlot<KW>*)&slots[parity], (const u64*)gcnt, k, g);
+    }
 }
 
 // phase 0: the walk kernel over tiles [tile_begin, tile_end); phase 1: the scalar kernel for the reads
-// it diverted.  The caller clears the workspace header (kmc_walk_prepare) before phase 0.
+// it diverted + the unfold of the dense snapshot counters.  `parity` selects the snapshot slot read
+// by this launch (the other one is written); the caller flips it after phase 1.  The caller clears the workspace header (kmc_walk_prepare) before phase 0.
 static inline int kmc_walk_prepare(hipStream_t st, void* ws) {
-    return hipMemsetAsync(ws, 0, sizeof(WalkWs), st) == hipSuccess ? KMC_OK : KMC_ERR_HIP;
+    return hipMemsetAsync(ws, 0, KMC_WALK_WS_PREFIX, st) == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
 static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool canon, const uint8_t* d_bases,
-                                  const u64* d_offsets, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, GTable g, int phase) {
+                                  const u64* d_offsets, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, int parity, GTable g, int phase) {
     if (n_reads >= (1ull << 32) || tile_end <= tile_begin) return KMC_ERR_ARG;
     WalkWs* hdr = (WalkWs*)ws;
-    u32* list = (u32*)((char*)ws + sizeof(WalkWs));
+    u32* list = (u32*)((char*)ws + KMC_WALK_WS_PREFIX);
+    u64* gcnt_ws = (u64*)((char*)ws + sizeof(WalkWs));
     const u64 n_tiles = tile_end - tile_begin;
     u64 want = (n_tiles + KMC_WALK_WAVES - 1) / KMC_WALK_WAVES;
     int grid = (int)(want < (u64)n_cu ? want : (u64)n_cu);  // one 160 KB workgroup per CU is resident
     if (grid < 1) grid = 1;
     if (KW == 1) {
-        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g, phase);
-        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g, phase);
+        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
+        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
     } else {
-        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g, phase);
-        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, memo, g, phase);
+        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
+        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
     }
     return hipGetLastError() == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }

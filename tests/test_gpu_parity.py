@@ -414,3 +414,32 @@ def test_garbage_after_the_batch_is_ignored(kmc, oracle):
                     with kmc.KmerCounter(k=k, algo=algo) as kc:
                         kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), 257, n, int(lens.max()))
                         assert kc.export().equals(want), (hex(tail_fill), n_extra, k, algo)
+
+
+@pytest.mark.parametrize("fasta_bytes,k,seed", [(1e9, 21, 1), (10e9, 31, 2), (10e9, 63, 2)])
+def test_baseline_config_sizes(kmc, oracle, fasta_bytes, k, seed):
+    """BASELINE.json configs 2, 3 and 5 at their full sizes (the oracle would need minutes), through
+    size-independent properties: analytic total, sortedness, two record shards == one batch
+    (shard invariance, exact table equality), and the exact key set -- every distinct k-mer of this
+    generator already occurs in the first 200k records, which the oracle does count."""
+    torch = pytest.importorskip("torch")
+    s = kmc.Synth(seed=seed)
+    n, _ = kmc.synth_records_for_bytes(s, int(fasta_bytes))
+    d_b = torch.empty(n * 400 + 64, dtype=torch.uint8, device="cuda")
+    d_o = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+    kmc.synth_reads_device(s, 0, n, d_b.data_ptr(), d_o.data_ptr())
+    hb, ho = kmc.synth_reads_host(s, 0, 200_000)
+    sample = oracle.count_kmers(hb, ho, k, True, method=1)
+    with kmc.KmerCounter(k=k) as kc:
+        kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, n * 400, 400)
+        t = kc.export()
+        assert kc.stats().algo_last == kmc.ALGO_WALK
+        assert t.n_total == n * (400 - k + 1)
+        assert np.array_equal(t.key_hi, sample.key_hi) and np.array_equal(t.key_lo, sample.key_lo)
+        assert np.all(t.count >= sample.count)
+        kc.reset()
+        h = (n // 2 // 64) * 64 + 17   # an odd cut, not on a tile boundary
+        kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), h, h * 400, 400)
+        d_o2 = (d_o[h:] - d_o[h]).contiguous()
+        kc.add_batch_device(d_b.data_ptr() + h * 400, d_o2.data_ptr(), n - h, (n - h) * 400, 400)
+        assert kc.export().equals(t)
