@@ -915,8 +915,23 @@ static int sort_view(kmc_ctx* c, u64 n) {
 extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    int rc = poll_and_settle(c);
+    int rc;
+    bool tried_fast = false;
+    if (c->runs.empty()) {
+        // speculative small-table finalize, queued behind whatever is still running
+        const size_t fb = (size_t)KMC_OCC_LIST_CAP * sizeof(u64);
+        rc = ensure(c, c->o_lo, fb); if (rc) return rc;
+        rc = ensure(c, c->o_cnt, fb); if (rc) return rc;
+        if (c->KW == 2) { rc = ensure(c, c->o_hi, fb); if (rc) return rc; }
+        GTable g = gtable_of(c, c->tab);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(1), dim3(1024), 0, c->stream, g, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+        else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(1), dim3(1024), 0, c->stream, g, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+        HIPCHK(c, hipGetLastError());
+        tried_fast = true;
+    }
+    rc = poll_and_settle(c);
     if (rc) return rc;
+    const bool fast_done = tried_fast && c->h_counters[KMC_CTR_FASTFIN] == 1;
     const u64 n_tab = c->h_counters[KMC_CTR_OCCUPIED];
     u64 n_runs_total = 0;
     for (auto& r : c->runs) n_runs_total += r.n;
@@ -924,7 +939,7 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
     u64 n_kmers = 0;
     const bool single_run = n_tab == 0 && c->runs.size() == 1;
     const bool lean_merge = !c->runs.empty() && c->KW == 1;  // merge by sorting (key, count) pairs directly
-    if (!single_run) {
+    if (!single_run && !fast_done) {
         if (!c->runs.empty()) {
             // a merge of big runs needs room: give back the sort path's scratch and the pooled buffers
             DevBuf* scratch[] = {&c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->s_head};
@@ -947,15 +962,8 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
     c->v_hi = c->KW == 2 ? (const u64*)c->o_hi.p : nullptr;
     c->v_lo = (const u64*)c->o_lo.p;
     c->v_cnt = (const u64*)c->o_cnt.p;
-    if (c->runs.empty() && n_tab > 0 && n_tab <= KMC_OCC_LIST_CAP) {
-        // small table: one single-workgroup kernel gathers, sorts and writes the view
-        HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM2], 0, sizeof(u64), c->stream));
-        GTable g = gtable_of(c, c->tab);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(1), dim3(1024), 0, c->stream, g, n_tab, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
-        else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(1), dim3(1024), 0, c->stream, g, n_tab, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
-        HIPCHK(c, hipGetLastError());
-        rc = poll(c);
-        if (rc) return rc;
+    if (fast_done) {
+        // small table: the single-workgroup kernel already gathered, sorted and wrote the view
         n_kmers = c->h_counters[KMC_CTR_SUM2];
     } else if (single_run) {
         // one sorted run and an empty table: it IS the sorted view (no copy)

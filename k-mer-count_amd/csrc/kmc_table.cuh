@@ -113,13 +113,21 @@ __global__ void kmc_sum_kernel(const u64* cnt, u64 n, u64* counters) {
 // the sorted view and the sum of counts -- instead of scanning the whole table, three library sort
 // launches and a gather.  This is the GPU form of the reference's final ordering step
 // (k-mer-count/src/main.rs:87) for the common case of a few thousand distinct keys.
+// It is launched speculatively right behind the count kernels: it reads the occupancy on the device
+// and gives up (FASTFIN = 0) unless the table is small and nothing spilled, so kmc_finalize needs a
+// single host synchronisation.
 template <int KW>
 __global__ __launch_bounds__(1024)
-void kmc_small_finalize_kernel(GTable g, u64 n, u64* __restrict__ out_hi, u64* __restrict__ out_lo, u64* __restrict__ out_cnt) {
+void kmc_small_finalize_kernel(GTable g, u64* __restrict__ out_hi, u64* __restrict__ out_lo, u64* __restrict__ out_cnt) {
     __shared__ u64 s_lo[KMC_OCC_LIST_CAP];
     __shared__ u64 s_hi[KW == 2 ? KMC_OCC_LIST_CAP : 1];
     __shared__ unsigned short s_ix[KMC_OCC_LIST_CAP];
     const int tid = threadIdx.x;
+    const u64 n = g.counters[KMC_CTR_OCCUPIED];
+    const bool ok = n > 0 && n <= KMC_OCC_LIST_CAP && g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0;
+    if (tid == 0) { g.counters[KMC_CTR_FASTFIN] = ok ? 1 : 0; g.counters[KMC_CTR_SUM2] = 0; }
+    if (!ok) return;
+    __syncthreads();
     u32 N = 1;
     while (N < n) N <<= 1;  // padded to a power of two with all-ones keys (sort last)
     for (u32 i = tid; i < N; i += 1024) {
