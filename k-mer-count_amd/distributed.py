@@ -128,14 +128,14 @@ def reduce_tables(local, owner, group=None):
     recv_hi, recv_lo, recv_cnt = exchange_pairs(cut(hi) if hi is not None else None, cut(lo), cut(cnt), group)
     got = 0
     keep = []  # keep the received tensors alive until the merge kernels have run
+    torch.cuda.current_stream(dev).synchronize()  # payload landed before the ctx stream reads it
     for p in range(world):
         m = int(recv_lo[p].numel())
         if not m:
             continue
-        rl, rc = recv_lo[p].contiguous(), recv_cnt[p].contiguous()
+        rl, rc = recv_lo[p].contiguous(), recv_cnt[p].contiguous()  # (views of the receive buffer: no copy)
         rh = recv_hi[p].contiguous() if recv_hi is not None else None
         keep.append((rl, rc, rh))
-        torch.cuda.current_stream(dev).synchronize()  # payload landed before the ctx stream reads it
         owner.merge_pairs_device(rh.data_ptr() if rh is not None else 0, rl.data_ptr(), rc.data_ptr(), m)
         got += m
     owner.finalize()
