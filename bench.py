@@ -59,11 +59,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    # KMC_BENCH_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a
+    # one-GPU box; RCCL refuses two ranks on one device).  The driver's multi-GPU run uses nccl.
+    backend = os.environ.get("KMC_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     # ---- resident input: this rank's shard of the seeded record stream -------------------------
     synth = kmc.Synth(seed=args.seed, pool=args.pool)
@@ -116,11 +124,21 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = kc.stats()
     algo_used = {1: "stream", 2: "walk", 3: "sort"}.get(st.algo_last, "?")
+    reduced = None
+    if world > 1:
+        # outside the timed region: the owner-partitioned result of the last step must account for
+        # every k-mer of every rank, and owners must not overlap (distinct keys add up)
+        own_nd, own_nt = owner.finalize()
+        t = torch.tensor([own_nd, own_nt], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        reduced = {"distinct_all_owners": int(t[0].item()), "kmers_all_owners": int(t[1].item())}
+        if reduced["kmers_all_owners"] != n_kmers * world:
+            raise SystemExit(f"reduce mismatch: owners hold {reduced['kmers_all_owners']} k-mers, expected {n_kmers * world}")
 
     # ---- roofline of the dominant kernel (this rank's launches; every rank runs the same shape) --
     algo_bytes = n_bases + 8 * (n_rec + 1)  # 1 B/base ASCII + the offsets array
@@ -181,7 +199,7 @@ def main():
                                                             "forward" if args.forward else "canonical", world),
                        "records_per_gpu": n_rec, "bases_per_gpu": n_bases, "kmers_per_gpu": n_kmers,
                        "distinct": int(nd), "algo": algo_used, "sharding": "records, one shard per GPU; RCCL all-to-all table reduce"
-                       if world > 1 else "single GPU"},
+                       if world > 1 else "single GPU", "reduced": reduced},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

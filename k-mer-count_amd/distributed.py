@@ -70,6 +70,9 @@ def all_to_all_v(send: Sequence[torch.Tensor], group=None) -> List[torch.Tensor]
         recv = torch.empty(sum(in_splits), dtype=torch.int64, device=dev)
         dist.all_to_all_single(recv, payload, output_split_sizes=in_splits, input_split_sizes=out_splits, group=group)
         return list(torch.split(recv, in_splits))
+    if dev.type != "cpu":
+        # gloo cannot move device tensors point-to-point: stage through the host (rehearsal path only)
+        return [t.to(dev) for t in all_to_all_v([t.cpu() for t in send], group)]
     gathered = [torch.empty_like(sizes_out) for _ in range(world)]
     dist.all_gather(gathered, sizes_out, group=group)
     in_splits = [int(g[rank]) for g in gathered]
