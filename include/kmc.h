@@ -92,6 +92,7 @@ typedef struct kmc_stats {
     double   kernel_ms_total;
     int32_t  algo_last;       /* kmc_algo actually used for the last batch */
     int32_t  launches_last;   /* count-kernel launches in the last batch */
+    uint64_t n_slabs_skipped; /* oversize slabs seen by kmc_merge_slabs_device (valid after kmc_finalize) */
 } kmc_stats;
 
 const char* kmc_version(void);
@@ -143,6 +144,29 @@ int kmc_export_device(kmc_ctx* ctx, const void** d_key_hi, const void** d_key_lo
 int kmc_partition_device(kmc_ctx* ctx, uint32_t n_parts, uint64_t* part_begin,
                          const void** d_key_hi, const void** d_key_lo, const void** d_count);
 uint32_t kmc_owner_of(uint64_t key_hi, uint64_t key_lo, uint32_t n_parts);
+
+/* Multi-GPU reduce for small tables: ONE fixed-size all-gather instead of size exchange +
+ * all-to-all (the reduce of main.rs:87's grouping across GPUs; for the generator's input a table is
+ * a few thousand keys, so the exchange is latency-bound and every host synchronisation counts).
+ * A slab holds up to slab_entries (key,count) pairs behind an 8-word header; kmc_slab_words gives
+ * its size in 64-bit words for this ctx's key width.  kmc_pack_slab_device (after kmc_finalize)
+ * writes this ctx's sorted table into d_slab, or marks the slab "oversize" when it has more than
+ * slab_entries keys.  kmc_merge_slabs_device adds, from n_slabs consecutive slabs (the all-gather
+ * result), every pair with kmc_owner_of(key, n_parts) == my_part; oversize slabs are skipped and
+ * counted in kmc_stats.n_slabs_skipped at the next kmc_finalize (the caller then moves those
+ * tables with kmc_partition_device + all-to-all + kmc_merge_pairs_device).  Both calls are
+ * asynchronous on the ctx stream and never synchronise with the host. */
+uint64_t kmc_slab_words(const kmc_ctx* ctx, uint64_t slab_entries);
+int kmc_pack_slab_device(kmc_ctx* ctx, void* d_slab, uint64_t slab_entries);
+int kmc_merge_slabs_device(kmc_ctx* ctx, const void* d_slabs, uint32_t n_slabs, uint64_t slab_entries,
+                           uint32_t my_part, uint32_t n_parts);
+
+/* Drop what the ctx has learned about its data source (the walk kernel's memo of the input's
+ * de Bruijn graph structure and the launch planner's new-keys-per-k-mer history); kmc_reset keeps
+ * both because later batches of the same source profit from them.  Counts are not affected. */
+#define KMC_FORGET_MEMO 1     /* the walk kernel's memo snapshot */
+#define KMC_FORGET_HISTORY 2  /* the launch planner's history (and the AUTO algorithm choice) */
+int kmc_forget_source(kmc_ctx* ctx, int what);
 
 int kmc_get_stats(const kmc_ctx* ctx, kmc_stats* out);
 

@@ -25,7 +25,8 @@ from typing import Iterable, Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkmc.so")
+# KMC_LIB_PATH: load another build of the same ABI (same-box A/B runs of kernel variants; tools/ab_bench.sh)
+LIB_PATH = os.environ.get("KMC_LIB_PATH") or os.path.join(_HERE, "libkmc.so")
 
 MODE_CONTIG, MODE_LR = 0, 1
 ALGO_AUTO, ALGO_STREAM, ALGO_WALK, ALGO_SORT = 0, 1, 2, 3
@@ -50,7 +51,7 @@ class Stats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_kmers", C.c_uint64), ("n_distinct", C.c_uint64),
                 ("table_capacity", C.c_uint64), ("n_spilled", C.c_uint64), ("n_batches", C.c_uint64),
                 ("kernel_ms_last", C.c_double), ("kernel_ms_total", C.c_double), ("algo_last", C.c_int32),
-                ("launches_last", C.c_int32)]
+                ("launches_last", C.c_int32), ("n_slabs_skipped", C.c_uint64)]
 
 
 class _Reads(C.Structure):
@@ -78,6 +79,7 @@ ABI_SYMBOLS = [
     "kmc_export_device", "kmc_partition_device", "kmc_owner_of", "kmc_get_stats", "kmc_count_file",
     "kmc_parse_fasta", "kmc_free_reads", "kmc_decode_key", "kmc_synth_records_for_bytes",
     "kmc_synth_reads_host", "kmc_synth_reads_device", "kmc_synth_write_fasta",
+    "kmc_slab_words", "kmc_pack_slab_device", "kmc_merge_slabs_device", "kmc_forget_source",
 ]
 
 _lib = None
@@ -132,6 +134,11 @@ def lib() -> C.CDLL:
     L.kmc_owner_of.argtypes = [u64, u64, u32]
     L.kmc_owner_of.restype = u32
     L.kmc_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.kmc_slab_words.argtypes = [vp, u64]
+    L.kmc_slab_words.restype = u64
+    L.kmc_pack_slab_device.argtypes = [vp, vp, u64]
+    L.kmc_merge_slabs_device.argtypes = [vp, vp, u32, u64, u32, u32]
+    L.kmc_forget_source.argtypes = [vp, i32]
     L.kmc_count_file.argtypes = [vp, C.c_char_p, pu64, pu64]
     L.kmc_parse_fasta.argtypes = [C.c_char_p, C.POINTER(_Reads), C.c_char_p, C.c_size_t]
     L.kmc_free_reads.argtypes = [C.POINTER(_Reads)]
@@ -254,6 +261,7 @@ class KmerCounter:
         if rc:
             raise KmcError(rc, L.kmc_last_error(None).decode())
         self._h = h
+        self.stream = int(stream) if stream else 0  # hipStream_t the ctx runs on (0: its own stream)
         self.k = 54 if mode == MODE_LR else int(k)
         self.mode = mode
         self.device = int(device)
@@ -334,6 +342,22 @@ class KmerCounter:
         a, b, c = C.c_void_p(), C.c_void_p(), C.c_void_p()
         self._chk(self._L.kmc_partition_device(self._h, n_parts, pb, C.byref(a), C.byref(b), C.byref(c)))
         return list(pb), a.value or 0, b.value or 0, c.value or 0
+
+    # -- multi-GPU reduce, small tables (one fixed-size all-gather; distributed.py) --
+    def slab_words(self, slab_entries: int) -> int:
+        return int(self._L.kmc_slab_words(self._h, int(slab_entries)))
+
+    def pack_slab_device(self, d_slab: int, slab_entries: int):
+        """After finalize(): this table as one fixed-size slab (or an 'oversize' marker)."""
+        self._chk(self._L.kmc_pack_slab_device(self._h, d_slab, int(slab_entries)))
+
+    def merge_slabs_device(self, d_slabs: int, n_slabs: int, slab_entries: int, my_part: int, n_parts: int):
+        """Add every pair of the gathered slabs that this rank owns; oversize slabs are skipped
+        and show up in stats().n_slabs_skipped after the next finalize()."""
+        self._chk(self._L.kmc_merge_slabs_device(self._h, d_slabs, int(n_slabs), int(slab_entries), int(my_part), int(n_parts)))
+
+    def forget_source(self, memo: bool = True, history: bool = False):
+        self._chk(self._L.kmc_forget_source(self._h, (1 if memo else 0) | (2 if history else 0)))
 
     def stats(self) -> Stats:
         s = Stats()

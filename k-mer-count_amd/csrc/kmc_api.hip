@@ -238,6 +238,7 @@ int poll(kmc_ctx* c) {
     c->pending = false;
     c->batch_pending = false;
     c->unpolled_adds = 0;
+    c->st.n_slabs_skipped = c->h_counters[KMC_CTR_SLABSKIP];
     {
         // share of k-mers the walk kernel had to count directly since the previous poll
         u64 d = c->h_counters[KMC_CTR_BADBASE], n = c->h_counters[KMC_CTR_KMERS];
@@ -1118,6 +1119,68 @@ extern "C" int kmc_partition_device(kmc_ctx* c, uint32_t n_parts, uint64_t* part
     if (d_key_hi) *d_key_hi = c->KW == 2 ? c->p_hi.p : nullptr;
     if (d_key_lo) *d_key_lo = c->p_lo.p;
     if (d_count) *d_count = c->p_cnt.p;
+    return KMC_OK;
+}
+
+extern "C" uint64_t kmc_slab_words(const kmc_ctx* c, uint64_t slab_entries) {
+    return c ? KMC_SLAB_HEADER + slab_entries * (u64)(c->KW + 1) : 0;
+}
+
+extern "C" int kmc_pack_slab_device(kmc_ctx* c, void* d_slab, uint64_t slab_entries) {
+    if (!c || !d_slab || !slab_entries) return c ? fail(c, KMC_ERR_ARG, "kmc_pack_slab_device: null slab or zero capacity") : KMC_ERR_ARG;
+    if (((uintptr_t)d_slab & 7) != 0) return fail(c, KMC_ERR_ARG, "d_slab must be 8-byte aligned");
+    if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_pack_slab_device before kmc_finalize");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    const u64 n = c->n_sorted;
+    const int grid = grid_for(c, std::max<u64>(std::min(n, slab_entries), KMC_SLAB_HEADER), 256);
+    if (c->KW == 1) hipLaunchKernelGGL(kmc_pack_slab_kernel<1>, dim3(grid), dim3(256), 0, c->stream, (const u64*)nullptr, c->v_lo, c->v_cnt, n, c->st.n_kmers, slab_entries, (u64*)d_slab);
+    else hipLaunchKernelGGL(kmc_pack_slab_kernel<2>, dim3(grid), dim3(256), 0, c->stream, c->v_hi, c->v_lo, c->v_cnt, n, c->st.n_kmers, slab_entries, (u64*)d_slab);
+    HIPCHK(c, hipGetLastError());
+    return KMC_OK;
+}
+
+extern "C" int kmc_merge_slabs_device(kmc_ctx* c, const void* d_slabs, uint32_t n_slabs, uint64_t slab_entries,
+                                      uint32_t my_part, uint32_t n_parts) {
+    if (!c) return KMC_ERR_ARG;
+    if (!d_slabs || !n_slabs || !slab_entries || !n_parts || my_part >= n_parts) return fail(c, KMC_ERR_ARG, "kmc_merge_slabs_device: bad argument");
+    if (((uintptr_t)d_slabs & 7) != 0) return fail(c, KMC_ERR_ARG, "d_slabs must be 8-byte aligned");
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    // room for the worst case (every pair of every slab new and owned here), accounted like
+    // kmc_merge_pairs_device so that a reset table needs no host synchronisation
+    const u64 n = (u64)n_slabs * slab_entries;
+    if (c->batch_pending || (c->h_counters[KMC_CTR_OCCUPIED] + c->unpolled_adds + n) * 2 > c->tab.cap) {
+        if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
+        u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
+        if ((occ + n) * 2 > c->tab.cap) {
+            int rc = grow_to(c, next_pow2((occ + n) * 2));
+            if (rc) return rc;
+        }
+    }
+    c->unpolled_adds += n;
+    c->sorted_valid = false;
+    GTable g = gtable_of(c, c->tab);
+    const u64 words = KMC_SLAB_HEADER + slab_entries * (u64)(c->KW + 1);
+    const int grid = grid_for(c, n, 256);
+    if (c->KW == 1) hipLaunchKernelGGL(kmc_merge_slabs_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (const u64*)d_slabs, n_slabs, words, slab_entries, my_part, n_parts);
+    else hipLaunchKernelGGL(kmc_merge_slabs_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (const u64*)d_slabs, n_slabs, words, slab_entries, my_part, n_parts);
+    HIPCHK(c, hipGetLastError());
+    c->pending = true;
+    return KMC_OK;
+}
+
+extern "C" int kmc_forget_source(kmc_ctx* c, int what) {
+    if (!c) return KMC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if ((what & KMC_FORGET_MEMO) && c->walk_memo.p) {
+        HIPCHK(c, hipMemsetAsync(c->walk_memo.p, 0, kmc_walk_memo_bytes(c->n_cu, c->KW), c->stream));  // tag 0 = no snapshot
+        c->memo_parity = 0;
+    }
+    if (what & KMC_FORGET_HISTORY) {
+        c->rho_hist = -1.0;
+        c->rho_last = c->rho_max = 0.0;
+        c->prefer_sort = false;
+        c->walk_overflowed = false;
+    }
     return KMC_OK;
 }
 

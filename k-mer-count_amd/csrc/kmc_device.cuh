@@ -20,6 +20,7 @@ enum { KMC_CTR_OCCUPIED = 0, KMC_CTR_SPILL = 1, KMC_CTR_ERR = 2, KMC_CTR_KMERS =
        KMC_CTR_OUT1 = 8, KMC_CTR_SUM1 = 9,  // second parity of OUT/SUM: a finalize clears the pair the next one uses
        KMC_CTR_SUM2 = 10,                   // sum of counts of a merged (table + sorted runs) view
        KMC_CTR_FASTFIN = 11,                // 1: the speculative small-table finalize produced the sorted view
+       KMC_CTR_SLABSKIP = 12,               // slabs kmc_merge_slabs_kernel skipped (oversize: payload not inline)
        KMC_CTR_N = 16 };
 
 // Global (HBM) open-addressing count table.  One-word keys (KW==1, k<=31) use key_lo only and

@@ -100,6 +100,49 @@ __global__ void kmc_owner_kernel(const u64* hi, const u64* lo, u64 n, u32 n_part
         owner_out[i] = kmc_owner(hi ? hi[i] : 0ull, lo[i], n_parts);
 }
 
+// ---- multi-GPU reduce, small tables: fixed-size slabs ------------------------------------------
+// A slab is what one rank contributes to ONE all-gather: an 8-word header followed by fixed-capacity
+// arrays, so every rank sends the same number of words and no size exchange (and no host
+// synchronisation) is needed.  Layout in u64 words, E = slab_entries:
+//   [0] n pairs in this slab, or KMC_SLAB_OVERSIZE when the table has more than E keys (then the
+//       payload is absent and the rank's table travels by the partitioned all-to-all instead)
+//   [1] sum of the counts   [2..7] reserved (0)
+//   [8, 8+E) key_lo   [8+E, 8+2E) count   [8+2E, 8+3E) key_hi (two-word keys only)
+#define KMC_SLAB_HEADER 8
+#define KMC_SLAB_OVERSIZE (~0ull)
+template <int KW>
+__global__ void kmc_pack_slab_kernel(const u64* __restrict__ hi, const u64* __restrict__ lo, const u64* __restrict__ cnt,
+                                     u64 n, u64 sum, u64 entries, u64* __restrict__ slab) {
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 < KMC_SLAB_HEADER) slab[i0] = i0 == 0 ? (n <= entries ? n : KMC_SLAB_OVERSIZE) : (i0 == 1 ? sum : 0ull);
+    if (n > entries) return;
+    for (u64 i = i0; i < n; i += (u64)gridDim.x * blockDim.x) {
+        slab[KMC_SLAB_HEADER + i] = lo[i];
+        slab[KMC_SLAB_HEADER + entries + i] = cnt[i];
+        if (KW == 2) slab[KMC_SLAB_HEADER + 2 * entries + i] = hi[i];
+    }
+}
+
+// The owner's side: of the n_slabs gathered slabs, add every pair whose owner(key) is `my_part`.
+template <int KW>
+__global__ void kmc_merge_slabs_kernel(GTable g, const u64* __restrict__ slabs, u32 n_slabs, u64 slab_words, u64 entries,
+                                       u32 my_part, u32 n_parts) {
+    const u64 total = (u64)n_slabs * entries;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (u64)gridDim.x * blockDim.x) {
+        const u64 sl = i / entries, j = i - sl * entries;
+        const u64* s = slabs + sl * slab_words;
+        const u64 n = s[0];
+        if (n == KMC_SLAB_OVERSIZE) {
+            if (j == 0) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_SLABSKIP], 1ull);
+            continue;
+        }
+        if (j >= n) continue;
+        const u64 klo = s[KMC_SLAB_HEADER + j], c = s[KMC_SLAB_HEADER + entries + j];
+        const u64 khi = KW == 2 ? s[KMC_SLAB_HEADER + 2 * entries + j] : 0ull;
+        if (c && kmc_owner(khi, klo, n_parts) == my_part) gtable_add<KW>(g, khi, klo, c);
+    }
+}
+
 // sum of n counts -> counters[KMC_CTR_SUM2]
 __global__ void kmc_sum_kernel(const u64* cnt, u64 n, u64* counters) {
     u64 a = 0;

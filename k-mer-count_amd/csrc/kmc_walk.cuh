@@ -42,6 +42,9 @@
 #define KMC_WALK_NLOG 10
 #define KMC_WALK_NCAP (1 << KMC_WALK_NLOG)
 #define KMC_WALK_BADWORDS 64
+#ifndef KMC_WALK_LPR
+#define KMC_WALK_LPR 4  // 16-byte loads per lane and round (two rounds in flight per wave)
+#endif
 
 // A node and its PRIMARY out-edge (the first 16-base continuation seen after this context),
 // direct-indexed by node id: the hot step is one ds_read_b64 of {plabel, psucc} + one ds_add.
@@ -397,15 +400,17 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         t.n_pieces = (u32)((t.B - t.A16 + 15) >> 4);
         return t;
     };
-    // Four coalesced 1 KiB wave-loads: pieces base + {0,64,128,192} + lane of the byte range that
-    // starts at A16.  Branch-free on purpose (straight-line code lets the compiler keep counted
-    // s_waitcnt vmcnt(N) and two sets in flight): a piece index past the end is clamped to the
+    // One round = KMC_WALK_LPR coalesced 1 KiB wave-loads: pieces base + 64*u + lane of the byte range
+    // that starts at A16.  Branch-free on purpose (straight-line code lets the compiler keep counted
+    // s_waitcnt vmcnt(N) and two rounds in flight): a piece index past the end is clamped to the
     // last piece -- that re-reads one cache line and is never stored.
+    constexpr int LPR = KMC_WALK_LPR;
+    constexpr u32 RP = 64u * LPR;  // pieces per round
     const u64 max_off = (n_bases - 1) & ~15ull;  // never touch a 16-byte piece that starts past the last base
-    auto issue4 = [&](uint4 (&v)[4], u64 A16, u32 last, u32 base) {
+    auto issue = [&](uint4 (&v)[LPR], u64 A16, u32 last, u32 base) {
         if (A16 > max_off) A16 = max_off;  // (a tile of empty reads at the very end of the batch)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < LPR; ++u) {
             u32 p = base + 64 * u + lane;
             p = p < last ? p : last;
             // streamed once: non-temporal (nt) loads measured +4 % over the default cache policy
@@ -415,60 +420,60 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         }
     };
     bool anybad = false;
-    auto consume4 = [&](const uint4 (&v)[4], const TileGeo& t, u32 base) {
+    // Encode one round into the staging area.  Hot path (every piece of the round exists, every
+    // byte is ACGT): no per-lane branch at all -- the "is anything not ACGT" test is ONE ballot per
+    // round; the exact per-piece check (which also ignores bytes outside this wave's range [A, B))
+    // runs only when that ballot fires.
+    auto consume = [&](const uint4 (&v)[LPR], const TileGeo& t, u32 base, u32 np_u) {
+        u32 xacc = 0;
+        if (base + RP <= np_u) {  // wave-uniform
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const u32 p = base + 64 * u + lane;
-            if (p < t.n_pieces) {
+            for (int u = 0; u < LPR; ++u) {
                 u32 x0, x1, x2, x3;
-                stage[p] = walk_encode16(v[u], x0, x1, x2, x3);
-                if ((x0 | x1 | x2 | x3) != 0) {
-                    // exact check, ignoring bytes outside this wave's range [A, B)
-                    u32 bad = nonzero_bytes4(x0) | (nonzero_bytes4(x1) << 4) | (nonzero_bytes4(x2) << 8) | (nonzero_bytes4(x3) << 12);
-                    const u64 pos = t.A16 + 16ull * p;
-                    if (pos < t.A) bad &= ~((1u << (u32)(t.A - pos)) - 1u);
-                    if (pos + 16 > t.B) bad &= (t.B > pos) ? ((1u << (u32)(t.B - pos)) - 1u) : 0u;
-                    if (bad) { atomicOr(&L.badbits[wv][p >> 5], 1u << (p & 31)); anybad = true; }
+                stage[base + 64 * u + lane] = walk_encode16(v[u], x0, x1, x2, x3);
+                xacc |= x0 | x1 | x2 | x3;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < LPR; ++u) {
+                const u32 p = base + 64 * u + lane;
+                if (p < t.n_pieces) {
+                    u32 x0, x1, x2, x3;
+                    stage[p] = walk_encode16(v[u], x0, x1, x2, x3);
+                    xacc |= x0 | x1 | x2 | x3;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(xacc != 0) != 0) {
+#pragma unroll
+            for (int u = 0; u < LPR; ++u) {
+                const u32 p = base + 64 * u + lane;
+                if (p < t.n_pieces) {
+                    u32 x0, x1, x2, x3;
+                    (void)walk_encode16(v[u], x0, x1, x2, x3);
+                    if ((x0 | x1 | x2 | x3) != 0) {
+                        // exact check, ignoring bytes outside this wave's range [A, B)
+                        u32 bad = nonzero_bytes4(x0) | (nonzero_bytes4(x1) << 4) | (nonzero_bytes4(x2) << 8) | (nonzero_bytes4(x3) << 12);
+                        const u64 pos = t.A16 + 16ull * p;
+                        if (pos < t.A) bad &= ~((1u << (u32)(t.A - pos)) - 1u);
+                        if (pos + 16 > t.B) bad &= (t.B > pos) ? ((1u << (u32)(t.B - pos)) - 1u) : 0u;
+                        if (bad) { atomicOr(&L.badbits[wv][p >> 5], 1u << (p & 31)); anybad = true; }
+                    }
                 }
             }
         }
     };
 
-    // A round = 256 pieces = 4 KiB per wave.  Two register sets with fixed roles (va: even rounds,
-    // vb: odd rounds) keep 4-8 KiB per wave in flight.  A tile is padded to an even number of
-    // rounds (a padding round re-reads the tile's last cache line and is never stored); the round
-    // after the padded end is round 0 of the NEXT tile, whose latency therefore hides behind this
-    // tile's step phase.  (Three sets / 12 KiB in flight measured slower: 128 VGPRs.)
-    uint4 va[4], vb[4];
-    TileGeo cur;
-    if (gw < n_tiles) { cur = tile_geo(gw); issue4(va, cur.A16, cur.n_pieces ? cur.n_pieces - 1 : 0, 0); }
-    for (u64 tile = gw; tile < n_tiles; tile += total_waves) {
+    // ---- step phase of one tile: every lane walks its own read through the memo ----
+    auto step_phase = [&](const TileGeo& t, u64 tile) {
         const u64 r = tile * 64 + lane;
-        const bool have = cur.have != 0;
-        const u64 a = cur.a, e = cur.e, A16 = cur.A16;
-        const u32 n_pieces = cur.n_pieces;
-        const bool has_next = tile + total_waves < n_tiles;
-        TileGeo nxt = cur;
-        if (has_next) nxt = tile_geo(tile + total_waves);
-
-        // ---- load phase: coalesced 16 B pieces -> 2-bit words in this wave's staging area ----
-        if (lane < KMC_WALK_BADWORDS) L.badbits[wv][lane] = 0;
-        anybad = false;
-        const u32 np_u = (u32)__builtin_amdgcn_readfirstlane((int)n_pieces);
-        const u32 cur_last = n_pieces ? n_pieces - 1 : 0, nxt_last = nxt.n_pieces ? nxt.n_pieces - 1 : 0;
-        for (u32 base = 0; base < np_u || base == 0; base += 512) {
-            issue4(vb, A16, cur_last, base + 256);
-            consume4(va, cur, base);
-            const bool more = base + 512 < np_u;  // wave-uniform
-            issue4(va, more ? A16 : nxt.A16, more ? cur_last : nxt_last, more ? base + 512 : 0u);
-            consume4(vb, cur, base + 256);
-        }
-        if (lane == 0) stage[n_pieces] = 0;  // the re-alignment reads one word past the last piece
+        const bool have = t.have != 0;
+        const u64 a = t.a, e = t.e, A16 = t.A16;
+        if (lane == 0) stage[t.n_pieces] = 0;  // the re-alignment reads one word past the last piece
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // ---- per-lane read ----
         u32 len_read = (u32)(e - a);
         bool mine = have && len_read > 0;
         if (__builtin_amdgcn_ballot_w64(anybad) != 0 && mine) {
@@ -497,16 +502,19 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         u32 s = s_root;
         WCtx dctx = {0, 0};
         u32 ddepth = 0;
-        u32 wc = mine ? stage[w0] : 0;
-        for (u32 t = 0; t < KMC_WALK_MAX_READ / KMC_WALK_STRIDE + 1; ++t) {
-            const bool act = t < nsteps;
+        // the staged words of my read are fetched one step ahead (they do not depend on the walk), so
+        // the only LDS round trip on the step-to-step critical path is the node lookup
+        const u32* sp = stage + (mine ? w0 : 0);
+        u32 wc = sp[0], wn = sp[1];
+        for (u32 tstep = 0; tstep < KMC_WALK_MAX_READ / KMC_WALK_STRIDE + 1; ++tstep) {
+            const bool act = tstep < nsteps;
             if (__builtin_amdgcn_ballot_w64(act) == 0) break;
             if (act) {
                 // next 16 bases of my read, re-aligned to its start
-                const u32 wn = stage[w0 + t + 1];
                 u32 label = alignbit(wn, wc, sh);
                 wc = wn;
-                const bool full = t < nfull;
+                wn = sp[tstep + 2];  // (at most 2 words past the read's last word: inside the staging area's slack; unused then)
+                const bool full = tstep < nfull;
                 WalkNode* np = reinterpret_cast<WalkNode*>(reinterpret_cast<char*>(L.node) + s);
                 const u64 pe = __hip_atomic_load(&np->prim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (full && (u32)pe == label && (u32)(pe >> 32) != 0) {
@@ -519,7 +527,48 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
             }
         }
         __builtin_amdgcn_wave_barrier();  // staging area is reused by the next tile
-        cur = nxt;
+    };
+
+    // The wave's loads form ONE stream of rounds across its tiles, and the two register sets
+    // alternate strictly along that stream: while round g is encoded out of one set, round g+1 -- the
+    // next round of this tile, or round 0 of the wave's next tile -- is already in flight in the
+    // other.  So a tile costs ceil(n_pieces / RP) rounds whatever their parity (the first version
+    // padded every tile to an even number: 8 instead of 6.25 rounds' worth of loads on 400-base
+    // reads), and the first round of the next tile hides behind this tile's step phase.
+    // (Three sets / 12 KiB in flight measured slower: 128 VGPRs.)
+    uint4 va[LPR], vb[LPR];
+    TileGeo cur, nxt;
+    u64 tile = gw;
+    bool live = gw < n_tiles;  // wave-uniform
+    bool has_next = false;
+    u32 rbase = 0;
+    if (live) { cur = tile_geo(tile); nxt = cur; issue(va, cur.A16, cur.n_pieces ? cur.n_pieces - 1 : 0, 0); }
+    auto half = [&](uint4 (&x)[LPR], uint4 (&y)[LPR]) {
+        const u32 np_u = (u32)__builtin_amdgcn_readfirstlane((int)cur.n_pieces);
+        if (rbase == 0) {  // tile entry
+            if (lane < KMC_WALK_BADWORDS) L.badbits[wv][lane] = 0;
+            anybad = false;
+            has_next = tile + total_waves < n_tiles;
+            if (has_next) nxt = tile_geo(tile + total_waves);
+        }
+        const bool last = rbase + RP >= np_u;  // wave-uniform: this is the tile's last round
+        const u32 cur_last = cur.n_pieces ? cur.n_pieces - 1 : 0, nxt_last = nxt.n_pieces ? nxt.n_pieces - 1 : 0;
+        issue(y, last ? nxt.A16 : cur.A16, last ? nxt_last : cur_last, last ? 0u : rbase + RP);
+        consume(x, cur, rbase, np_u);
+        if (last) {
+            step_phase(cur, tile);
+            cur = nxt;
+            tile += total_waves;
+            rbase = 0;
+            live = has_next;
+        } else {
+            rbase += RP;
+        }
+    };
+    while (live) {
+        half(va, vb);
+        if (!live) break;
+        half(vb, va);
     }
     nk = wave_sum_u64(nk);
     ndirect = wave_sum_u64(ndirect);

@@ -9,8 +9,14 @@ per-GPU count tables.  Open-addressing layouts differ per GPU, so the tables are
 its own xGMI link, so all links are busy at once), and the owner merges what it receives
 (kmc_merge_pairs_device).  The result stays partitioned by owner.
 
+Tables of generator-style input are a few thousand keys, so that exchange is latency-bound: small
+tables travel in ONE fixed-size all-gather of "slabs" instead (reduce_tables), with no size
+exchange and no host synchronisation in between; the partitioned all-to-all remains for tables
+that do not fit a slab.
+
 The exchange itself only moves torch tensors, so the same code runs on gloo/CPU tensors in the
-world_size-2 CPU tests.
+world_size-2 CPU tests (tests/test_distributed_cpu.py drives reduce_tables with a CPU stand-in for
+the two ctxs that restates the slab layout in numpy).
 """
 from __future__ import annotations
 
@@ -46,10 +52,18 @@ class _DevArray:
 
 
 def device_view(ptr: int, n: int, device) -> torch.Tensor:
-    """int64 torch view of n 64-bit words at device address ptr (bits are what matter)."""
+    """int64 torch view of n 64-bit words at device address ptr (bits are what matter).
+    (device "cpu": host address -- used by the CPU stand-in of the world_size-2 gloo tests.)"""
     if n == 0 or not ptr:
         return torch.empty(0, dtype=torch.int64, device=device)
+    if torch.device(device).type == "cpu":
+        import ctypes
+        return torch.from_numpy(np.frombuffer((ctypes.c_int64 * n).from_address(ptr), dtype=np.int64))
     return torch.as_tensor(_DevArray(ptr, n), device=device)
+
+
+def _dev_of(ctx) -> torch.device:
+    return torch.device("cuda", ctx.device) if ctx.device >= 0 else torch.device("cpu")
 
 
 def all_to_all_v(send: Sequence[torch.Tensor], group=None) -> List[torch.Tensor]:
@@ -114,24 +128,89 @@ def exchange_pairs(parts_hi: Optional[Sequence[torch.Tensor]], parts_lo: Sequenc
     return recv_hi, recv_lo, recv_cnt
 
 
-def reduce_tables(local, owner, group=None):
+SLAB_ENTRIES = 8192  # pairs per slab of the one-all-gather path (the generator's input: 2.6-6.4 k keys)
+
+
+def _same_stream(ctx, dev) -> bool:
+    """True when the ctx queues its work on torch's current stream: then kernels and collectives
+    are ordered on the device and no host synchronisation is needed between them."""
+    return bool(ctx.stream) and ctx.stream == torch.cuda.current_stream(dev).cuda_stream
+
+
+def _order(ctx, dev):
+    """Order torch's current stream and the ctx stream with respect to each other."""
+    if dev.type == "cuda" and not _same_stream(ctx, dev):
+        torch.cuda.current_stream(dev).synchronize()
+
+
+_slab_cache = {}
+
+
+def _slab_buffers(words: int, world: int, dev):
+    key = (words, world, str(dev))
+    if key not in _slab_cache:
+        _slab_cache[key] = (torch.zeros(words, dtype=torch.int64, device=dev),
+                            torch.zeros(words * world, dtype=torch.int64, device=dev))
+    return _slab_cache[key]
+
+
+def _all_gather_slabs(gathered: torch.Tensor, slab: torch.Tensor, group=None):
+    if dist.get_backend(group) == "nccl" or slab.device.type == "cpu":
+        dist.all_gather_into_tensor(gathered, slab, group=group)
+    else:  # gloo with device tensors (one-GPU rehearsal): stage through the host
+        h = torch.empty(gathered.shape, dtype=gathered.dtype)
+        dist.all_gather_into_tensor(h, slab.cpu(), group=group)
+        gathered.copy_(h)
+
+
+def reduce_tables(local, owner, group=None, slab_entries: int = SLAB_ENTRIES):
     """The RCCL count-table reduce.  `local`: KmerCounter holding this rank's counts;
     `owner`: a second (reset) KmerCounter on the same GPU that receives the keys this rank owns.
     Afterwards owner.export() is this rank's partition of the global table.
-    Returns (pairs_sent, pairs_received)."""
+
+    Small tables (at most `slab_entries` keys -- every table of generator-style input) move in ONE
+    fixed-size all-gather of slabs (kmc_pack_slab_device / kmc_merge_slabs_device): no size
+    exchange, and when both ctxs run on torch's current stream no host synchronisation besides the
+    two finalizes.  A rank whose table is larger marks its slab "oversize"; every rank sees that
+    in the gathered headers (stats().n_slabs_skipped of the owner) and those tables then travel by
+    the owner-partitioned all-to-all.  Returns (pairs_sent, pairs_received_or_owned)."""
     world = dist.get_world_size(group)
-    dev = torch.device("cuda", local.device)
+    rank = dist.get_rank(group)
+    dev = _dev_of(local)
+    n, _ = local.finalize()
+    words = local.slab_words(slab_entries)
+    slab, gathered = _slab_buffers(words, world, dev)
+    local.pack_slab_device(slab.data_ptr(), slab_entries)
+    _order(local, dev)                      # slab written before the collective reads it
+    _all_gather_slabs(gathered, slab, group)
+    _order(owner, dev)                      # gathered slabs landed before the owner's stream reads them
+    owner.merge_slabs_device(gathered.data_ptr(), world, slab_entries, rank, world)
+    got, _ = owner.finalize()
+    if owner.stats().n_slabs_skipped == 0:
+        return n, got
+    # some table did not fit its slab: those ranks send theirs by the partitioned all-to-all
+    # (every rank takes part; a rank whose table travelled inline sends nothing)
+    return n, _reduce_tables_a2a(local, owner, group, send=n > slab_entries)
+
+
+def _reduce_tables_a2a(local, owner, group=None, send: bool = True):
+    """Owner-partitioned all-to-all of (key, count) pairs (tables of any size)."""
+    world = dist.get_world_size(group)
+    dev = _dev_of(local)
     local.finalize()
     pb, d_hi, d_lo, d_cnt = local.partition_device(world)
+    if not send:
+        pb = [0] * (world + 1)
     n = pb[world]
     lo = device_view(d_lo, n, dev)
     cnt = device_view(d_cnt, n, dev)
-    hi = device_view(d_hi, n, dev) if d_hi else None
+    hi = device_view(d_hi, n, dev) if local.k > 31 else None
     cut = lambda t: [t[pb[p]:pb[p + 1]] for p in range(world)]
     recv_hi, recv_lo, recv_cnt = exchange_pairs(cut(hi) if hi is not None else None, cut(lo), cut(cnt), group)
     got = 0
     keep = []  # keep the received tensors alive until the merge kernels have run
-    torch.cuda.current_stream(dev).synchronize()  # payload landed before the ctx stream reads it
+    if dev.type == "cuda":
+        torch.cuda.current_stream(dev).synchronize()  # payload landed before the ctx stream reads it
     for p in range(world):
         m = int(recv_lo[p].numel())
         if not m:
@@ -141,5 +220,5 @@ def reduce_tables(local, owner, group=None):
         keep.append((rl, rc, rh))
         owner.merge_pairs_device(rh.data_ptr() if rh is not None else 0, rl.data_ptr(), rc.data_ptr(), m)
         got += m
-    owner.finalize()
-    return n, got
+    got_total, _ = owner.finalize()
+    return got_total

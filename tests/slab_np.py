@@ -1,0 +1,131 @@
+"""Test-side numpy restatement of the slab layout of the multi-GPU reduce
+(k-mer-count_amd/csrc/kmc_table.cuh: kmc_pack_slab_kernel / kmc_merge_slabs_kernel) and a CPU
+stand-in for a kmc ctx that speaks the same protocol, so that distributed.reduce_tables can be
+driven by world_size-2 gloo processes without a GPU.  Test infrastructure only."""
+import ctypes as C
+import importlib
+
+import numpy as np
+
+HEADER = 8
+OVERSIZE = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def slab_words(key_words: int, entries: int) -> int:
+    return HEADER + entries * (key_words + 1)
+
+
+def pack(key_hi, key_lo, count, key_words: int, entries: int) -> np.ndarray:
+    s = np.zeros(slab_words(key_words, entries), np.uint64)
+    n = len(key_lo)
+    s[1] = np.uint64(int(np.sum(count, dtype=np.uint64))) if n else 0
+    if n > entries:
+        s[0] = OVERSIZE
+        return s
+    s[0] = n
+    s[HEADER:HEADER + n] = key_lo
+    s[HEADER + entries:HEADER + entries + n] = count
+    if key_words == 2:
+        s[HEADER + 2 * entries:HEADER + 2 * entries + n] = key_hi
+    return s
+
+
+def unpack(slab: np.ndarray, key_words: int, entries: int):
+    """(hi, lo, cnt) of one slab, or None when it is marked oversize."""
+    if slab[0] == OVERSIZE:
+        return None
+    n = int(slab[0])
+    lo = slab[HEADER:HEADER + n].copy()
+    cnt = slab[HEADER + entries:HEADER + entries + n].copy()
+    hi = slab[HEADER + 2 * entries:HEADER + 2 * entries + n].copy() if key_words == 2 else np.zeros(n, np.uint64)
+    return hi, lo, cnt
+
+
+def merge_sorted(his, los, cnts):
+    """sum counts of equal (hi, lo) keys; sorted ascending."""
+    hi = np.concatenate(his) if his else np.zeros(0, np.uint64)
+    lo = np.concatenate(los) if los else np.zeros(0, np.uint64)
+    c = np.concatenate(cnts) if cnts else np.zeros(0, np.uint64)
+    if hi.size == 0:
+        return hi, lo, c
+    order = np.lexsort((lo, hi))
+    hi, lo, c = hi[order], lo[order], c[order]
+    new = np.ones(hi.size, bool)
+    new[1:] = (hi[1:] != hi[:-1]) | (lo[1:] != lo[:-1])
+    idx = np.cumsum(new) - 1
+    out = np.zeros(int(idx[-1]) + 1, np.uint64)
+    np.add.at(out, idx, c)
+    return hi[new], lo[new], out
+
+
+class _Stats:
+    n_slabs_skipped = 0
+    n_distinct = 0
+    n_kmers = 0
+
+
+class CpuCtx:
+    """Stands in for KmerCounter in distributed.reduce_tables: same method names and meaning,
+    'device' addresses are host addresses (device = -1)."""
+
+    def __init__(self, k: int, table=None):
+        self.k = k
+        self.kw = 1 if k <= 31 else 2
+        self.device = -1
+        self.stream = 0
+        z = np.zeros(0, np.uint64)
+        self.hi, self.lo, self.cnt = (table.key_hi, table.key_lo, table.count) if table is not None else (z, z, z)
+        self._pending = []
+        self._skipped = 0
+        self._keep = []
+        self._kd = importlib.import_module("k-mer-count_amd.distributed")
+
+    def finalize(self):
+        if self._pending:
+            self.hi, self.lo, self.cnt = merge_sorted([self.hi] + [p[0] for p in self._pending], [self.lo] + [p[1] for p in self._pending],
+                                                      [self.cnt] + [p[2] for p in self._pending])
+            self._pending = []
+        return len(self.lo), int(np.sum(self.cnt, dtype=np.uint64))
+
+    def stats(self):
+        s = _Stats()
+        s.n_slabs_skipped = self._skipped
+        s.n_distinct = len(self.lo)
+        s.n_kmers = int(np.sum(self.cnt, dtype=np.uint64))
+        return s
+
+    def slab_words(self, entries):
+        return slab_words(self.kw, entries)
+
+    @staticmethod
+    def _host(ptr, n):
+        return np.frombuffer((C.c_uint64 * n).from_address(ptr), dtype=np.uint64)
+
+    def pack_slab_device(self, ptr, entries):
+        self._host(ptr, self.slab_words(entries))[:] = pack(self.hi, self.lo, self.cnt, self.kw, entries)
+
+    def merge_slabs_device(self, ptr, n_slabs, entries, my_part, n_parts):
+        w = self.slab_words(entries)
+        all_ = self._host(ptr, w * n_slabs)
+        for i in range(n_slabs):
+            u = unpack(all_[i * w:(i + 1) * w], self.kw, entries)
+            if u is None:
+                self._skipped += 1
+                continue
+            hi, lo, cnt = u
+            mine = self._kd.owner_np(hi, lo, n_parts) == my_part
+            self._pending.append((hi[mine], lo[mine], cnt[mine]))
+
+    def partition_device(self, n_parts):
+        own = self._kd.owner_np(self.hi, self.lo, n_parts)
+        order = np.argsort(own, kind="stable")
+        self._keep = [np.ascontiguousarray(a[order]) for a in (self.hi, self.lo, self.cnt)]
+        pb = [int(np.searchsorted(own[order], p)) for p in range(n_parts)] + [len(order)]
+        ptr = lambda a: a.ctypes.data if a.size else 0
+        return pb, (ptr(self._keep[0]) if self.kw == 2 else 0), ptr(self._keep[1]), ptr(self._keep[2])
+
+    def merge_pairs_device(self, p_hi, p_lo, p_cnt, n):
+        lo = self._host(p_lo, n).copy()
+        cnt = self._host(p_cnt, n).copy()
+        hi = self._host(p_hi, n).copy() if p_hi else np.zeros(n, np.uint64)
+        self._pending.append((hi, lo, cnt))

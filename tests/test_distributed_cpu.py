@@ -64,6 +64,59 @@ def _worker(rank, port, k, tmpdir):
         dist.destroy_process_group()
 
 
+def _worker_reduce(rank, port, k, slab_entries, tmpdir):
+    """distributed.reduce_tables itself (slab all-gather, and the all-to-all behind it when a table
+    does not fit its slab), the two ctxs replaced by the numpy stand-in of tests/slab_np.py."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    try:
+        kd = importlib.import_module("k-mer-count_amd.distributed")
+        import oracle_py
+        import slab_np
+        bases, offs = oracle_py.parse_fasta(SAMPLE)
+        n_reads = len(offs) - 1
+        # uneven shards, so that with a small slab only ONE rank is oversize (mixed case)
+        cut = 2  # (2 records: at most 2 x 370 distinct 31-mers)
+        first, cnt = (0, cut) if rank == 0 else (cut, n_reads - cut)
+        sb = bases[int(offs[first]):int(offs[first + cnt])]
+        so = offs[first:first + cnt + 1] - offs[first]
+        local = slab_np.CpuCtx(k, oracle_py.count_kmers(sb, so, k, True))
+        owner = slab_np.CpuCtx(k)
+        sent, got = kd.reduce_tables(local, owner, slab_entries=slab_entries)
+        nd, nt = owner.finalize()
+        assert got == nd and sent == len(local.lo)
+        assert np.all(kd.owner_np(owner.hi, owner.lo, WORLD) == rank)
+        np.savez(os.path.join(tmpdir, f"owned{rank}.npz"), hi=owner.hi, lo=owner.lo, cnt=owner.cnt,
+                 skipped=owner.stats().n_slabs_skipped, n_local=len(local.lo))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("k,slab_entries", [(31, 8192), (63, 8192), (31, 2000), (63, 16)])
+def test_world2_reduce_tables_slab_and_fallback(oracle, tmp_path, k, slab_entries):
+    port = 31000 + (os.getpid() + 7 * k + slab_entries) % 2000
+    mp.spawn(_worker_reduce, args=(port, k, slab_entries, str(tmp_path)), nprocs=WORLD, join=True)
+    parts = [np.load(tmp_path / f"owned{r}.npz") for r in range(WORLD)]
+    import slab_np
+    hi, lo, cnt = slab_np.merge_sorted([p["hi"] for p in parts], [p["lo"] for p in parts], [p["cnt"] for p in parts])
+    bases, offs = oracle.parse_fasta(SAMPLE)
+    want = oracle.count_kmers(bases, offs, k, True)
+    assert np.array_equal(hi, want.key_hi) and np.array_equal(lo, want.key_lo) and np.array_equal(cnt, want.count)
+    assert sum(len(p["lo"]) for p in parts) == want.n_distinct  # owners are disjoint
+    # the case really exercised what its name says
+    n_over = sum(1 for p in parts if int(p["n_local"]) > slab_entries)
+    assert all(int(p["skipped"]) == n_over for p in parts)
+    if slab_entries == 8192:
+        assert n_over == 0
+    if slab_entries == 2000:
+        assert n_over == 1  # one table inline, one by all-to-all
+    if slab_entries == 16:
+        assert n_over == 2
+
+
 @pytest.mark.parametrize("k", [21, 63])
 def test_world2_reduce_equals_single_table(oracle, tmp_path, k):
     port = 29000 + (os.getpid() + k) % 2000

@@ -1,6 +1,7 @@
 """GPU parity: the HIP path, called through the C ABI, against the CPU oracle (bit-exact --
 integer work), the committed golden fixtures, and size-independent properties."""
 import json
+import importlib
 import os
 
 import numpy as np
@@ -320,6 +321,100 @@ def test_rccl_reduce_single_rank(kmc, oracle):
                 sent, got = kd.reduce_tables(local, owner)
                 assert sent == got == want.n_distinct
                 assert owner.export().equals(want)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_slab_pack_and_merge_kernels(kmc, oracle):
+    """kmc_pack_slab_device / kmc_merge_slabs_device against the numpy restatement of the slab
+    layout (tests/slab_np.py): three shard tables -> three slabs -> every owner merges its share;
+    the union is the table of everything.  One table is made too large for its slab: it must be
+    marked oversize, skipped by the merge and counted."""
+    torch = pytest.importorskip("torch")
+    import slab_np
+    bases, offs = oracle.parse_fasta(SAMPLE)
+    n_reads = len(offs) - 1
+    cuts = [0, 3, 70, n_reads]
+    E = 4096
+    for k in (31, 63):
+        kw = 1 if k <= 31 else 2
+        shards, ctxs = [], []
+        for i in range(3):
+            sb = bases[int(offs[cuts[i]]):int(offs[cuts[i + 1]])]
+            so = offs[cuts[i]:cuts[i + 1] + 1] - offs[cuts[i]]
+            shards.append(oracle.count_kmers(sb, so, k, True))
+            kc = kmc.KmerCounter(k=k)
+            kc.add_batch(sb, so)
+            kc.finalize()
+            ctxs.append(kc)
+        words = ctxs[0].slab_words(E)
+        assert words == slab_np.slab_words(kw, E)
+        # garbage first: the pack kernel must write every word it owns (header + n pairs)
+        gathered = torch.full((3 * words,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device="cuda")
+        for i, kc in enumerate(ctxs):
+            kc.pack_slab_device(gathered.data_ptr() + 8 * words * i, E)
+            kc.finalize()  # (synchronises the ctx stream)
+        host = gathered.cpu().numpy().view(np.uint64)
+        for i, t in enumerate(shards):
+            got = slab_np.unpack(host[i * words:(i + 1) * words], kw, E)
+            assert got is not None and int(host[i * words]) == t.n_distinct and int(host[i * words + 1]) == t.n_total
+            assert np.array_equal(got[0], t.key_hi) and np.array_equal(got[1], t.key_lo) and np.array_equal(got[2], t.count)
+        want = oracle.count_kmers(bases, offs, k, True)
+        owned = []
+        for part in range(3):
+            with kmc.KmerCounter(k=k) as ow:
+                ow.merge_slabs_device(gathered.data_ptr(), 3, E, part, 3)
+                t = ow.export()
+                assert ow.stats().n_slabs_skipped == 0
+                assert np.all(importlib.import_module("k-mer-count_amd.distributed").owner_np(t.key_hi, t.key_lo, 3) == part)
+                owned.append(t)
+        hi, lo, cnt = slab_np.merge_sorted([t.key_hi for t in owned], [t.key_lo for t in owned], [t.count for t in owned])
+        assert np.array_equal(hi, want.key_hi) and np.array_equal(lo, want.key_lo) and np.array_equal(cnt, want.count)
+        assert sum(t.n_distinct for t in owned) == want.n_distinct
+        # oversize: shard 2 has more than 64 keys
+        small = torch.zeros(3 * ctxs[0].slab_words(64), dtype=torch.int64, device="cuda")
+        w64 = ctxs[0].slab_words(64)
+        for i, kc in enumerate(ctxs):
+            kc.pack_slab_device(small.data_ptr() + 8 * w64 * i, 64)
+            kc.finalize()
+        hs = small.cpu().numpy().view(np.uint64)
+        n_over = sum(1 for t in shards if t.n_distinct > 64)
+        assert n_over >= 1 and sum(1 for i in range(3) if hs[i * w64] == slab_np.OVERSIZE) == n_over
+        with kmc.KmerCounter(k=k) as ow:
+            ow.merge_slabs_device(small.data_ptr(), 3, 64, 0, 1)
+            t = ow.export()
+            assert ow.stats().n_slabs_skipped == n_over
+            inline = [sh for sh in shards if sh.n_distinct <= 64]
+            assert t.n_total == sum(sh.n_total for sh in inline)
+        for kc in ctxs:
+            kc.close()
+
+
+def test_rccl_reduce_small_tables_on_torch_stream(kmc, oracle):
+    """The path bench.py --gpus N takes for generator-style input: both ctxs run on a torch stream,
+    the tables travel in one all-gather of slabs, no host synchronisation in between (one-rank nccl
+    group here; the driver's 8-GPU run is the real thing)."""
+    torch = pytest.importorskip("torch")
+    import torch.distributed as dist
+    kd = importlib.import_module("k-mer-count_amd.distributed")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = str(30500 + os.getpid() % 1000)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        bases, offs = oracle.parse_fasta(SAMPLE)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for k in (31, 63):
+                want = oracle.count_kmers(bases, offs, k, True)
+                with kmc.KmerCounter(k=k, stream=st.cuda_stream) as local, kmc.KmerCounter(k=k, stream=st.cuda_stream) as owner:
+                    assert kd._same_stream(local, torch.device("cuda", 0))
+                    for rep in range(3):  # repeated steps reuse the slab buffers
+                        local.reset(); owner.reset()
+                        local.add_batch(bases, offs)
+                        sent, got = kd.reduce_tables(local, owner)
+                        assert sent == got == want.n_distinct and owner.stats().n_slabs_skipped == 0
+                        assert owner.export().equals(want)
     finally:
         dist.destroy_process_group()
 
