@@ -185,6 +185,17 @@ typedef struct kmc_reads {
 int  kmc_parse_fasta(const char* path, kmc_reads* out, char* errbuf, size_t errbuf_len);
 void kmc_free_reads(kmc_reads* r);
 
+/* Streaming form of the reader: the file is handed out in chunks of about chunk_bytes of FASTA text
+ * (0 = 256 MiB), each ending at a record boundary, parsed by worker threads.  out->bases/offsets
+ * point into the stream's own buffers and stay valid until the next call on the stream (do NOT
+ * pass them to kmc_free_reads).  *eof is set to 1 with the last chunk.  This is what a host
+ * program (the Rust main() of INTEGRATION.md) feeds to kmc_add_batch chunk by chunk;
+ * kmc_count_file uses the same reader internally and overlaps parsing with upload and counting. */
+typedef struct kmc_fasta_stream kmc_fasta_stream;
+int  kmc_fasta_stream_open(const char* path, uint64_t chunk_bytes, kmc_fasta_stream** out, char* errbuf, size_t errbuf_len);
+int  kmc_fasta_stream_next(kmc_fasta_stream* s, kmc_reads* out, int* eof, char* errbuf, size_t errbuf_len);
+void kmc_fasta_stream_close(kmc_fasta_stream* s);
+
 /* Decode a key into klen ASCII characters (no terminator). */
 void kmc_decode_key(uint64_t key_hi, uint64_t key_lo, int klen, char* out);
 

@@ -80,6 +80,7 @@ ABI_SYMBOLS = [
     "kmc_parse_fasta", "kmc_free_reads", "kmc_decode_key", "kmc_synth_records_for_bytes",
     "kmc_synth_reads_host", "kmc_synth_reads_device", "kmc_synth_write_fasta",
     "kmc_slab_words", "kmc_pack_slab_device", "kmc_merge_slabs_device", "kmc_forget_source",
+    "kmc_fasta_stream_open", "kmc_fasta_stream_next", "kmc_fasta_stream_close",
 ]
 
 _lib = None
@@ -143,6 +144,10 @@ def lib() -> C.CDLL:
     L.kmc_parse_fasta.argtypes = [C.c_char_p, C.POINTER(_Reads), C.c_char_p, C.c_size_t]
     L.kmc_free_reads.argtypes = [C.POINTER(_Reads)]
     L.kmc_free_reads.restype = None
+    L.kmc_fasta_stream_open.argtypes = [C.c_char_p, u64, C.POINTER(vp), C.c_char_p, C.c_size_t]
+    L.kmc_fasta_stream_next.argtypes = [vp, C.POINTER(_Reads), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+    L.kmc_fasta_stream_close.argtypes = [vp]
+    L.kmc_fasta_stream_close.restype = None
     L.kmc_decode_key.argtypes = [u64, u64, i32, C.c_char_p]
     L.kmc_decode_key.restype = None
     L.kmc_synth_records_for_bytes.argtypes = [C.POINTER(Synth), u64, pu64]
@@ -238,6 +243,33 @@ def parse_fasta(path: str) -> Tuple[np.ndarray, np.ndarray]:
     finally:
         L.kmc_free_reads(C.byref(rd))
     return bases, offsets
+
+
+def stream_fasta(path: str, chunk_bytes: int = 0):
+    """Streaming form of the host reader: yields (bases, offsets) per chunk of about chunk_bytes of
+    FASTA text, each ending at a record boundary (copies: the stream reuses its buffers)."""
+    L = lib()
+    h = C.c_void_p()
+    eb = C.create_string_buffer(256)
+    rc = L.kmc_fasta_stream_open(os.fsencode(path), int(chunk_bytes), C.byref(h), eb, 256)
+    if rc:
+        raise KmcError(rc, eb.value.decode() or L.kmc_status_string(rc).decode())
+    try:
+        while True:
+            rd = _Reads()
+            eof = C.c_int(0)
+            rc = L.kmc_fasta_stream_next(h, C.byref(rd), C.byref(eof), eb, 256)
+            if rc:
+                raise KmcError(rc, eb.value.decode() or L.kmc_status_string(rc).decode())
+            nb, nr = int(rd.n_bases), int(rd.n_reads)
+            bases = (np.frombuffer((C.c_uint8 * nb).from_address(C.addressof(rd.bases.contents)), dtype=np.uint8).copy()
+                     if nb else np.zeros(0, np.uint8))
+            offsets = np.frombuffer((C.c_uint64 * (nr + 1)).from_address(C.addressof(rd.offsets.contents)), dtype=np.uint64).copy()
+            yield bases, offsets
+            if eof.value:
+                break
+    finally:
+        L.kmc_fasta_stream_close(h)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -6,6 +6,7 @@
 // the HIP runtime has no device, kmc_create fails.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <cstring>
@@ -26,6 +27,7 @@
 #include "kmc_walk.cuh"
 #include "kmc_lr.cuh"
 #include "kmc_sort.cuh"
+#include "kmc_ingest.h"
 
 namespace {
 
@@ -1190,8 +1192,8 @@ extern "C" int kmc_get_stats(const kmc_ctx* c, kmc_stats* out) {
     return KMC_OK;
 }
 
-extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
-    if (!c || !path) return KMC_ERR_ARG;
+// Whole file through kmc_parse_fasta, then batches of <= 1 GiB (fallback when the file cannot be mapped)
+static int count_file_whole(kmc_ctx* c, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
     kmc_reads rd;
     char eb[256] = {0};
     int rc = kmc_parse_fasta(path, &rd, eb, sizeof(eb));
@@ -1206,7 +1208,6 @@ extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct
             }
         }
     }
-    // batches of at most ~1 GiB of bases, cut at read boundaries
     const u64 BATCH = 1ull << 30;
     u64 r0 = 0;
     std::vector<u64> offs;
@@ -1219,6 +1220,77 @@ extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct
         r0 = r1;
     }
     kmc_free_reads(&rd);
+    if (rc) return rc;
+    return kmc_finalize(c, n_distinct, n_total);
+}
+
+// FASTA path in, table out (the reference's File::open + Reader + record loop, main.rs:44-46,58-62,
+// feeding the window loop).  Pipeline: the streaming reader (kmc_ingest.h) parses chunk j+1 on the
+// host cores into one of two pinned buffers while the GPU uploads and counts chunk j; the reader's
+// per-thread pieces go straight to their dense place in the device buffer, so the host never
+// stitches or copies the sequence a second time.
+extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
+    if (!c || !path) return KMC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    u64 chunk_bytes = 256ull << 20;
+    if (const char* e = getenv("KMC_INGEST_CHUNK_BYTES")) { u64 v = strtoull(e, nullptr, 10); if (v) chunk_bytes = v; }
+    KmcFastaIngest ing;
+    std::string err;
+    int rc = ing.open(path, chunk_bytes, &err);
+    if (rc == KMC_ERR_IO && err != "Error during opening the file") return count_file_whole(c, path, n_distinct, n_total);  // (not mappable)
+    if (rc) return fail(c, rc, "%s: %s", path, err.c_str());
+    const u64 cap = ing.chunk_capacity();
+    struct Pinned { uint8_t* bases = nullptr; u64* offs = nullptr; u64 offs_cap = 0; hipEvent_t ev = nullptr; bool busy = false; } pin[2];
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(c->stream);
+        for (auto& p : pin) {
+            if (p.bases) (void)hipHostFree(p.bases);
+            if (p.offs) (void)hipHostFree(p.offs);
+            if (p.ev) (void)hipEventDestroy(p.ev);
+        }
+    };
+    auto body = [&]() -> int {
+        KmcIngestChunk ck;
+        const bool lr = c->cfg.mode == KMC_MODE_LR;
+        for (int j = 0;; ++j) {
+            Pinned& p = pin[j & 1];
+            if (!p.bases) {
+                HIPCHK(c, hipHostMalloc((void**)&p.bases, (size_t)cap));
+                HIPCHK(c, hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
+            }
+            if (p.busy) { HIPCHK(c, hipEventSynchronize(p.ev)); p.busy = false; }  // its upload two chunks ago has finished
+            int r;
+            try { r = ing.next(p.bases, lr, &ck, &err); } catch (const std::bad_alloc&) { return fail(c, KMC_ERR_NOMEM, "out of memory while parsing %s", path); }
+            if (r) return fail(c, r, "%s: %s", path, err.c_str());
+            if (lr && ck.bad_byte >= 0) return fail(c, KMC_ERR_ALPHABET, "Unexpected charactor %c appears", ck.bad_byte);  // main.rs:23
+            if (ck.n_reads) {
+                if (p.offs_cap < ck.n_reads + 1) {
+                    if (p.offs) { HIPCHK(c, hipHostFree(p.offs)); p.offs = nullptr; }
+                    p.offs_cap = (ck.n_reads + 1) * 5 / 4 + 1024;
+                    HIPCHK(c, hipHostMalloc((void**)&p.offs, (size_t)p.offs_cap * sizeof(u64)));
+                }
+                memcpy(p.offs, ck.offsets.data(), (size_t)(ck.n_reads + 1) * sizeof(u64));
+                // settle the previous batch first (it may still read the staging buffers; its kernels finished
+                // long ago -- this chunk took longer to parse), then queue upload + count without waiting
+                if (c->pending) { r = poll_and_settle(c); if (r) return r; }
+                r = ensure(c, c->st_bases, ck.n_bases + 64);
+                if (r) return r;
+                r = ensure(c, c->st_offsets, (ck.n_reads + 1) * sizeof(u64));
+                if (r) return r;
+                for (const auto& pc : ck.pieces)
+                    HIPCHK(c, hipMemcpyAsync((uint8_t*)c->st_bases.p + pc.dst_off, p.bases + pc.src_off, (size_t)pc.n_bytes, hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipMemcpyAsync(c->st_offsets.p, p.offs, (size_t)(ck.n_reads + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+                HIPCHK(c, hipEventRecord(p.ev, c->stream));
+                p.busy = true;
+                r = count_batch_device(c, (const uint8_t*)c->st_bases.p, (const u64*)c->st_offsets.p, ck.n_reads, ck.n_bases, ck.max_read_len);
+                if (r) return r;
+            }
+            if (ck.eof) break;
+        }
+        return KMC_OK;
+    };
+    rc = body();
+    cleanup();
     if (rc) return rc;
     return kmc_finalize(c, n_distinct, n_total);
 }

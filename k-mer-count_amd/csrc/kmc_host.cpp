@@ -177,6 +177,226 @@ extern "C" int kmc_parse_fasta(const char* path, kmc_reads* out, char* errbuf, s
     }
 }
 
+// ---- streaming reader (kmc_ingest.h) -----------------------------------------------------------
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include "kmc_ingest.h"
+
+namespace {
+
+struct PieceOut {
+    uint64_t src_off = 0, n_bytes = 0;
+    std::vector<uint64_t> rec_start;  // local: sequence bytes of this piece that precede the record
+    std::vector<uint8_t> rec_blank;
+    bool bad_first_line = false;
+    int bad_byte = -1;
+};
+
+// lines of text[b, e) (b is a line start; the last line may end at e without '\n')
+void parse_piece(const char* text, uint64_t b, uint64_t e, bool file_start, bool check_alphabet, uint8_t* out, PieceOut* po) {
+    const char* p = text + b;
+    const char* const end = text + e;
+    uint8_t* o = out;
+    bool in_record = false;
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        if (le > p && *p == '>') {
+            const char* t = le;
+            while (t > p + 1 && is_space((unsigned char)t[-1])) t--;
+            po->rec_start.push_back((uint64_t)(o - out));
+            po->rec_blank.push_back(t - p <= 1);
+            in_record = true;
+        } else {
+            if (file_start && !in_record) { po->bad_first_line = true; break; }
+            const char* t = le;
+            while (t > p && is_space((unsigned char)t[-1])) t--;
+            const size_t n = (size_t)(t - p);
+            memcpy(o, p, n);
+            if (check_alphabet && po->bad_byte < 0) {
+                for (size_t i = 0; i < n; ++i) {
+                    const uint8_t c = (uint8_t)p[i];
+                    if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { po->bad_byte = c; break; }
+                }
+            }
+            o += n;
+        }
+        if (!nl) break;
+        p = nl + 1;
+    }
+    po->n_bytes = (uint64_t)(o - out);
+}
+
+}  // namespace
+
+KmcFastaIngest::~KmcFastaIngest() {
+    if (map_ && size_) munmap((void*)map_, (size_t)size_);
+}
+
+int KmcFastaIngest::open(const char* path, uint64_t chunk_bytes, std::string* err) {
+    int fd = ::open(path, O_RDONLY);
+    if (fd < 0) { if (err) *err = "Error during opening the file"; return KMC_ERR_IO; }
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); if (err) *err = "not a regular file"; return KMC_ERR_IO; }
+    size_ = (uint64_t)st.st_size;
+    if (size_) {
+        void* m = mmap(nullptr, (size_t)size_, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { ::close(fd); size_ = 0; if (err) *err = "cannot map the file"; return KMC_ERR_IO; }
+        map_ = (const char*)m;
+        (void)madvise(m, (size_t)size_, MADV_SEQUENTIAL);
+    }
+    ::close(fd);
+    chunk_bytes_ = std::max<uint64_t>(chunk_bytes, 1);
+    unsigned hw = std::thread::hardware_concurrency();
+    threads_ = std::max(1u, std::min(hw ? hw : 1u, 32u));
+    // chunk boundaries: the first record start ("\n>") at or after every multiple of chunk_bytes
+    cuts_.assign(1, 0);
+    uint64_t at = 0;
+    while (size_ - at > chunk_bytes_) {
+        uint64_t q = at + chunk_bytes_;
+        uint64_t cut = size_;
+        while (q < size_) {
+            const char* nl = (const char*)memchr(map_ + q, '\n', (size_t)(size_ - q));
+            if (!nl) break;
+            const uint64_t after = (uint64_t)(nl - map_) + 1;
+            if (after < size_ && map_[after] == '>') { cut = after; break; }
+            q = after;
+        }
+        if (cut >= size_) break;
+        cuts_.push_back(cut);
+        at = cut;
+    }
+    cuts_.push_back(size_);
+    cap_ = 64;
+    for (size_t i = 0; i + 1 < cuts_.size(); ++i) cap_ = std::max<uint64_t>(cap_, cuts_[i + 1] - cuts_[i] + 64);
+    next_cut_ = 0;
+    done_ = false;
+    return KMC_OK;
+}
+
+uint64_t KmcFastaIngest::chunk_capacity() const { return cap_; }
+
+int KmcFastaIngest::next(uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* ck, std::string* err) {
+    ck->pieces.clear();
+    ck->offsets.assign(1, 0);
+    ck->n_reads = ck->n_bases = ck->max_read_len = 0;
+    ck->bad_byte = -1;
+    ck->eof = true;
+    if (done_ || next_cut_ + 1 >= cuts_.size()) { done_ = true; return KMC_OK; }
+    const uint64_t cb = cuts_[next_cut_], ce = cuts_[next_cut_ + 1];
+    next_cut_++;
+    // segments of >= 4 MiB, snapped forward to line starts
+    const uint64_t len = ce - cb;
+    uint64_t nseg = std::min<uint64_t>(threads_, std::max<uint64_t>(1, len >> 22));
+    std::vector<uint64_t> sb((size_t)nseg + 1);
+    sb[0] = cb;
+    for (uint64_t i = 1; i < nseg; ++i) {
+        uint64_t q = cb + len * i / nseg;
+        if (q < sb[(size_t)i - 1]) q = sb[(size_t)i - 1];
+        const char* nl = q < ce ? (const char*)memchr(map_ + q - 1, '\n', (size_t)(ce - q + 1)) : nullptr;  // line start: byte after a '\n' at >= q-1
+        sb[(size_t)i] = nl ? (uint64_t)(nl - map_) + 1 : ce;
+    }
+    sb[(size_t)nseg] = ce;
+    std::vector<PieceOut> po((size_t)nseg);
+    try {
+        std::vector<std::thread> th;
+        for (uint64_t i = 1; i < nseg; ++i) {
+            po[(size_t)i].src_off = sb[(size_t)i] - cb;
+            th.emplace_back(parse_piece, map_, sb[(size_t)i], sb[(size_t)i + 1], false, check_alphabet, out_buf + po[(size_t)i].src_off, &po[(size_t)i]);
+        }
+        parse_piece(map_, sb[0], sb[1], cb == 0, check_alphabet, out_buf, &po[0]);
+        for (auto& t : th) t.join();
+    } catch (const std::system_error&) {
+        if (err) *err = "cannot start parser threads";
+        return KMC_ERR_NOMEM;
+    }
+    if (po[0].bad_first_line) { if (err) *err = "Expected > at record start."; done_ = true; return KMC_ERR_FORMAT; }
+    uint64_t base = 0;
+    std::vector<uint8_t> blank;
+    ck->offsets.clear();
+    for (auto& p : po) {
+        for (size_t j = 0; j < p.rec_start.size(); ++j) { ck->offsets.push_back(base + p.rec_start[j]); blank.push_back(p.rec_blank[j]); }
+        if (p.n_bytes) ck->pieces.push_back(KmcIngestPiece{p.src_off, p.n_bytes, base});
+        if (ck->bad_byte < 0 && p.bad_byte >= 0) ck->bad_byte = p.bad_byte;
+        base += p.n_bytes;
+    }
+    uint64_t nrec = ck->offsets.size();
+    ck->offsets.push_back(base);
+    ck->eof = next_cut_ + 1 >= cuts_.size();
+    // Record::is_empty(): a record with empty header and no sequence ends the input (main.rs:60-62)
+    for (uint64_t i = 0; i < nrec; ++i) {
+        if (blank[(size_t)i] && ck->offsets[(size_t)i + 1] == ck->offsets[(size_t)i]) {
+            nrec = i;
+            base = ck->offsets[(size_t)i];
+            ck->offsets.resize((size_t)nrec + 1);
+            // drop / shorten the pieces past the cut
+            std::vector<KmcIngestPiece> keep;
+            for (auto& pc : ck->pieces) {
+                if (pc.dst_off >= base) continue;
+                if (pc.dst_off + pc.n_bytes > base) pc.n_bytes = base - pc.dst_off;
+                keep.push_back(pc);
+            }
+            ck->pieces.swap(keep);
+            ck->eof = true;
+            done_ = true;
+            break;
+        }
+    }
+    if (ck->eof) done_ = true;
+    ck->n_reads = nrec;
+    ck->n_bases = base;
+    uint64_t m = 0;
+    for (uint64_t i = 0; i < nrec; ++i) m = std::max<uint64_t>(m, ck->offsets[(size_t)i + 1] - ck->offsets[(size_t)i]);
+    ck->max_read_len = m;
+    return KMC_OK;
+}
+
+// ---- public streaming form: dense host buffers, one chunk at a time -----------------------------
+struct kmc_fasta_stream {
+    KmcFastaIngest ing;
+    KmcIngestChunk ck;
+    std::vector<uint8_t> buf;
+};
+
+extern "C" int kmc_fasta_stream_open(const char* path, uint64_t chunk_bytes, kmc_fasta_stream** out, char* errbuf, size_t errbuf_len) {
+    if (!path || !out) return KMC_ERR_ARG;
+    *out = nullptr;
+    kmc_fasta_stream* s = new (std::nothrow) kmc_fasta_stream();
+    if (!s) return KMC_ERR_NOMEM;
+    std::string err;
+    int rc = s->ing.open(path, chunk_bytes ? chunk_bytes : (256ull << 20), &err);
+    if (rc) { set_err(errbuf, errbuf_len, err.c_str()); delete s; return rc; }
+    try { s->buf.resize((size_t)s->ing.chunk_capacity()); } catch (const std::bad_alloc&) { delete s; set_err(errbuf, errbuf_len, "out of memory"); return KMC_ERR_NOMEM; }
+    *out = s;
+    return KMC_OK;
+}
+
+extern "C" int kmc_fasta_stream_next(kmc_fasta_stream* s, kmc_reads* out, int* eof, char* errbuf, size_t errbuf_len) {
+    if (!s || !out) return KMC_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    std::string err;
+    int rc;
+    try {
+        rc = s->ing.next(s->buf.data(), false, &s->ck, &err);
+    } catch (const std::bad_alloc&) { set_err(errbuf, errbuf_len, "out of memory"); return KMC_ERR_NOMEM; }
+    if (rc) { set_err(errbuf, errbuf_len, err.c_str()); return rc; }
+    // dense form: the pieces move left, in order (destination never passes a later piece's source)
+    for (auto& pc : s->ck.pieces)
+        if (pc.dst_off != pc.src_off) memmove(s->buf.data() + pc.dst_off, s->buf.data() + pc.src_off, (size_t)pc.n_bytes);
+    out->bases = s->buf.data();
+    out->offsets = s->ck.offsets.data();
+    out->n_reads = s->ck.n_reads;
+    out->n_bases = s->ck.n_bases;
+    out->max_read_len = s->ck.max_read_len;
+    if (eof) *eof = s->ck.eof ? 1 : 0;
+    return KMC_OK;
+}
+
+extern "C" void kmc_fasta_stream_close(kmc_fasta_stream* s) { delete s; }
+
 extern "C" void kmc_free_reads(kmc_reads* r) {
     if (!r) return;
     free(r->bases);

@@ -43,7 +43,10 @@
 #define KMC_WALK_NCAP (1 << KMC_WALK_NLOG)
 #define KMC_WALK_BADWORDS 64
 #ifndef KMC_WALK_LPR
-#define KMC_WALK_LPR 4  // 16-byte loads per lane and round (two rounds in flight per wave)
+// 16-byte loads per lane and round (two rounds = 5-10 KiB in flight per wave).  Same-box A/B on the
+// benchmark batch (10 GB FASTA, k=31): 3 -> 1.53-1.55 ms, 4 -> 1.48-1.53, 5 -> 1.44-1.48, 6 -> 1.46-1.48
+// (a 64 x 400-base tile is exactly 5 rounds of 5).
+#define KMC_WALK_LPR 5
 #endif
 
 // A node and its PRIMARY out-edge (the first 16-base continuation seen after this context),
@@ -535,7 +538,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     // other.  So a tile costs ceil(n_pieces / RP) rounds whatever their parity (the first version
     // padded every tile to an even number: 8 instead of 6.25 rounds' worth of loads on 400-base
     // reads), and the first round of the next tile hides behind this tile's step phase.
-    // (Three sets / 12 KiB in flight measured slower: 128 VGPRs.)
+    // (Issuing the first tile's loads before the LDS initialisation measured 0.5 % slower, not faster.)
     uint4 va[LPR], vb[LPR];
     TileGeo cur, nxt;
     u64 tile = gw;

@@ -162,3 +162,65 @@ def test_host_fasta_reader_multi_segment(kmc, oracle, tmp_path):
     b1, o1 = kmc.parse_fasta(str(q))
     b2, o2 = oracle.parse_fasta(str(q))
     assert o1.tolist() == [0, 35_000_000, 50_000_000] and np.array_equal(o1, o2) and np.array_equal(b1, b2)
+
+
+def _stream_all(kmc, path, chunk_bytes):
+    """The streaming reader's chunks concatenated into the whole-file form."""
+    bs, os_, base, n_chunks = [], [np.zeros(1, np.uint64)], 0, 0
+    for b, o in kmc.stream_fasta(path, chunk_bytes):
+        assert int(o[0]) == 0 and int(o[-1]) == b.shape[0]
+        bs.append(b)
+        os_.append(o[1:] + np.uint64(base))
+        base += int(b.shape[0])
+        n_chunks += 1
+    return (np.concatenate(bs) if bs else np.zeros(0, np.uint8)), np.concatenate(os_), n_chunks
+
+
+def test_streaming_reader_matches_oracle(kmc, oracle, tmp_path):
+    """kmc_fasta_stream_* (what kmc_count_file feeds the GPU from): every chunking of a file gives
+    the whole-file reader's result -- chunks end at record starts, worker pieces are snapped to
+    line starts, CRLF, blank lines, missing final newline, the empty-record terminator."""
+    for cb in (1, 100, 437, 5000, 0):
+        b1, o1, n = _stream_all(kmc, SAMPLE, cb)
+        b2, o2 = oracle.parse_fasta(SAMPLE)
+        assert np.array_equal(b1, b2) and np.array_equal(o1, o2), cb
+        assert n == (200 if cb == 1 else n) and (cb != 0 or n == 1)
+    cases = [b">r1 desc\nACGT  \r\nAC\n\n>r2\n>r3\nGG", b"", b">a\n", b">a\nAC\n>\n>b\nGG\n", b">x y z\nAAAA\nCCCC",
+             b">a\r\nAC\r\n>b\r\nGT\r\n", b">a\nAC\n\n>b\n\nGG\n>\n\n>c\nTT\n", b">\n>b\nGG\n", b">a\nA>C\n>b\nG\n"]
+    for i, data in enumerate(cases):
+        p = tmp_path / f"s{i}.fasta"
+        p.write_bytes(data)
+        b2, o2 = oracle.parse_fasta(str(p))
+        for cb in (1, 3, 7, 0):
+            b1, o1, _ = _stream_all(kmc, str(p), cb)
+            assert np.array_equal(b1, b2) and np.array_equal(o1, o2), (data, cb)
+    bad = tmp_path / "sbad.fasta"
+    bad.write_bytes(b"ACGT\n>r\nAC\n")
+    with pytest.raises(kmc.KmcError) as e:
+        list(kmc.stream_fasta(str(bad), 4))
+    assert e.value.status == kmc.ERR_FORMAT and "Expected > at record start." in str(e.value)
+    with pytest.raises(kmc.KmcError) as e:
+        list(kmc.stream_fasta(str(tmp_path / "nope.fasta")))
+    assert e.value.status == kmc.ERR_IO
+
+
+def test_streaming_reader_multi_thread_chunks(kmc, oracle, tmp_path):
+    """Chunks above 8 MiB are parsed by several threads (pieces of >= 4 MiB): generator-style text,
+    then one 20 MB line, CRLF endings and no trailing newline."""
+    exe = os.path.join(ROOT, "bin", "kmc-genfasta")
+    p = tmp_path / "big.fasta"
+    with open(p, "wb") as f:
+        subprocess.run([exe, "--bytes", "60000000", "--seed", "12"], stdout=f, check=True)
+    b2, o2 = oracle.parse_fasta(str(p))
+    for cb in (0, 25_000_000, 9_000_000):
+        b1, o1, n = _stream_all(kmc, str(p), cb)
+        assert np.array_equal(o1, o2) and np.array_equal(b1, b2), cb
+        assert n == (1 if cb == 0 else -(-60_000_000 // cb)) or n >= 2
+    rng = np.random.default_rng(4)
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 50_000_000)].tobytes()
+    q = tmp_path / "long.fasta"
+    q.write_bytes(b">a\r\n" + seq[:20_000_000] + b"\r\n" + seq[20_000_000:35_000_000] + b"\n>b x\n" + seq[35_000_000:])
+    b2, o2 = oracle.parse_fasta(str(q))
+    for cb in (0, 10_000_000):
+        b1, o1, _ = _stream_all(kmc, str(q), cb)
+        assert o1.tolist() == [0, 35_000_000, 50_000_000] and np.array_equal(o1, o2) and np.array_equal(b1, b2)

@@ -335,7 +335,7 @@ def test_slab_pack_and_merge_kernels(kmc, oracle):
     bases, offs = oracle.parse_fasta(SAMPLE)
     n_reads = len(offs) - 1
     cuts = [0, 3, 70, n_reads]
-    E = 4096
+    E = 8192  # (sample.fasta has 6,140 distinct 63-mers)
     for k in (31, 63):
         kw = 1 if k <= 31 else 2
         shards, ctxs = [], []

@@ -86,6 +86,15 @@ def test_host_reader_equals_oracle_reader(kmc, oracle, tmp_path_factory, records
         return
     b1, o1 = kmc.parse_fasta(str(p))
     assert np.array_equal(o1, o2) and np.array_equal(b1, b2)
+    # the streaming reader, at a chunk size that cuts this text in several places
+    for cb in (1, 9, 0):
+        bs, os_, base = [], [np.zeros(1, np.uint64)], 0
+        for b, o in kmc.stream_fasta(str(p), cb):
+            bs.append(b)
+            os_.append(o[1:] + np.uint64(base))
+            base += int(b.shape[0])
+        b3 = np.concatenate(bs) if bs else np.zeros(0, np.uint8)
+        assert np.array_equal(np.concatenate(os_), o2) and np.array_equal(b3, b2), cb
 
 
 @settings(max_examples=40, deadline=None)
