@@ -9,8 +9,9 @@ Workload (BASELINE.json config 3, the one the metric is quoted on): the parsed f
 10 GB synthetic FASTA with the distribution of the reference's random_fasta_generator.py:5-15
 (seeded re-creation, kmc_synth_*), k = 31, canonical, resident in HBM before the timed region.
 One "step" = one pass of the hot path over the resident batch: reset the count table, count
-every k-mer (HIP kernel), compact + sort the table on the device; with N > 1 also the RCCL
-count-table reduce (k-mer-count_amd/distributed.py).  Weak scaling: every rank holds its own 10 GB-equivalent shard (different
+every k-mer (HIP kernel), compact + sort the table on the device; with N > 1 the per-GPU tables are
+reduced over RCCL first (k-mer-count_amd/distributed.py) and every rank compacts + sorts the
+partition of the global table it owns.  Weak scaling: every rank holds its own 10 GB-equivalent shard (different
 records of the same seeded stream), no data-path collective while counting.
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant (count) kernel: algorithmic
@@ -44,6 +45,7 @@ def main():
     ap.add_argument("--algo", default="auto", choices=["auto", "stream", "walk", "sort"])
     ap.add_argument("--forward", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cold", action="store_true", help="skip the untimed cold-memo steps after the timed region (profiling runs)")
     ap.add_argument("--cpu-sample-records", type=int, default=5_000_000, help="bounded CPU-baseline sample (~10-15 s of one core)")
     args = ap.parse_args()
 
@@ -103,12 +105,13 @@ def main():
         if world > 1:
             owner.reset()
             with torch.cuda.stream(side):
-                kdist.reduce_tables(kc, owner)  # finalizes kc, one all-gather of slabs, merge, finalizes owner
-            nd, nt = kc.stats().n_distinct, kc.stats().n_kmers
+                # pack the live table, one all-gather of slabs, owner merge, owner finalize (compact + sort):
+                # the product of a step is the owner-partitioned sorted table; checked after the timed region
+                _, nd = kdist.reduce_tables(kc, owner, report_sent=False)
         else:
             nd, nt = kc.finalize()
-        if nt != n_kmers:
-            raise SystemExit(f"count mismatch: table sums to {nt}, expected {n_kmers}")
+            if nt != n_kmers:
+                raise SystemExit(f"count mismatch: table sums to {nt}, expected {n_kmers}")
         if record:
             st = kc.stats()
             kernel_ms.append(st.kernel_ms_last)
@@ -139,7 +142,7 @@ def main():
     # first (kmc_forget_source).  The memo is graph STRUCTURE learned from earlier launches (no
     # counts); timed steps reuse it, as every batch after the first of a real file does.
     cold_ms = []
-    if algo_used == "walk":
+    if algo_used == "walk" and not args.no_cold:
         for _ in range(3):
             kc.forget_source(memo=True, history=False)
             step(False)
@@ -214,7 +217,7 @@ def main():
                                    "k=%d, %s, %dxMI355X" % (fasta_bytes / 1e9, args.seed, args.pool, k,
                                                             "forward" if args.forward else "canonical", world),
                        "records_per_gpu": n_rec, "bases_per_gpu": n_bases, "kmers_per_gpu": n_kmers,
-                       "distinct": int(nd), "algo": algo_used, "sharding": "records, one shard per GPU; RCCL table reduce (one all-gather of fixed-size slabs)"
+                       "distinct": int(reduced["distinct_all_owners"]) if reduced else int(nd), "algo": algo_used, "sharding": "records, one shard per GPU; RCCL table reduce (one all-gather of fixed-size slabs)"
                        if world > 1 else "single GPU", "reduced": reduced},
             "roofline": roofline,
             "cpu_baseline": cpu,

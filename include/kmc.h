@@ -149,9 +149,10 @@ uint32_t kmc_owner_of(uint64_t key_hi, uint64_t key_lo, uint32_t n_parts);
  * all-to-all (the reduce of main.rs:87's grouping across GPUs; for the generator's input a table is
  * a few thousand keys, so the exchange is latency-bound and every host synchronisation counts).
  * A slab holds up to slab_entries (key,count) pairs behind an 8-word header; kmc_slab_words gives
- * its size in 64-bit words for this ctx's key width.  kmc_pack_slab_device (after kmc_finalize)
- * writes this ctx's sorted table into d_slab, or marks the slab "oversize" when it has more than
- * slab_entries keys.  kmc_merge_slabs_device adds, from n_slabs consecutive slabs (the all-gather
+ * its size in 64-bit words for this ctx's key width.  kmc_pack_slab_device writes this ctx's table
+ * into d_slab -- the sorted view after kmc_finalize, otherwise straight from the live table
+ * (unsorted; no finalize and no host synchronisation needed first) -- or marks the slab "oversize"
+ * when the table has more than slab_entries keys (live table: also more than 8192).  kmc_merge_slabs_device adds, from n_slabs consecutive slabs (the all-gather
  * result), every pair with kmc_owner_of(key, n_parts) == my_part; oversize slabs are skipped and
  * counted in kmc_stats.n_slabs_skipped at the next kmc_finalize (the caller then moves those
  * tables with kmc_partition_device + all-to-all + kmc_merge_pairs_device).  Both calls are
@@ -164,6 +165,12 @@ int kmc_merge_slabs_device(kmc_ctx* ctx, const void* d_slabs, uint32_t n_slabs, 
 /* Drop what the ctx has learned about its data source (the walk kernel's memo of the input's
  * de Bruijn graph structure and the launch planner's new-keys-per-k-mer history); kmc_reset keeps
  * both because later batches of the same source profit from them.  Counts are not affected. */
+/* Wait for everything queued on the ctx and read its device counters: brings kmc_stats up to date
+ * (n_kmers, kernel_ms_*) and lets the launch planner learn from the batch just counted -- what
+ * kmc_finalize does on the way, for callers that reset a ctx without finalizing it (multi-GPU
+ * reduce: the live table is packed and shipped, only the owner's table is finalized). */
+int kmc_poll(kmc_ctx* ctx);
+
 #define KMC_FORGET_MEMO 1     /* the walk kernel's memo snapshot */
 #define KMC_FORGET_HISTORY 2  /* the launch planner's history (and the AUTO algorithm choice) */
 int kmc_forget_source(kmc_ctx* ctx, int what);

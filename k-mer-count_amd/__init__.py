@@ -80,7 +80,7 @@ ABI_SYMBOLS = [
     "kmc_parse_fasta", "kmc_free_reads", "kmc_decode_key", "kmc_synth_records_for_bytes",
     "kmc_synth_reads_host", "kmc_synth_reads_device", "kmc_synth_write_fasta",
     "kmc_slab_words", "kmc_pack_slab_device", "kmc_merge_slabs_device", "kmc_forget_source",
-    "kmc_fasta_stream_open", "kmc_fasta_stream_next", "kmc_fasta_stream_close",
+    "kmc_fasta_stream_open", "kmc_fasta_stream_next", "kmc_fasta_stream_close", "kmc_poll",
 ]
 
 _lib = None
@@ -140,6 +140,7 @@ def lib() -> C.CDLL:
     L.kmc_pack_slab_device.argtypes = [vp, vp, u64]
     L.kmc_merge_slabs_device.argtypes = [vp, vp, u32, u64, u32, u32]
     L.kmc_forget_source.argtypes = [vp, i32]
+    L.kmc_poll.argtypes = [vp]
     L.kmc_count_file.argtypes = [vp, C.c_char_p, pu64, pu64]
     L.kmc_parse_fasta.argtypes = [C.c_char_p, C.POINTER(_Reads), C.c_char_p, C.c_size_t]
     L.kmc_free_reads.argtypes = [C.POINTER(_Reads)]
@@ -387,6 +388,10 @@ class KmerCounter:
         """Add every pair of the gathered slabs that this rank owns; oversize slabs are skipped
         and show up in stats().n_slabs_skipped after the next finalize()."""
         self._chk(self._L.kmc_merge_slabs_device(self._h, d_slabs, int(n_slabs), int(slab_entries), int(my_part), int(n_parts)))
+
+    def poll(self):
+        """Synchronise and read the device counters (stats, launch-planner history) without finalizing."""
+        self._chk(self._L.kmc_poll(self._h))
 
     def forget_source(self, memo: bool = True, history: bool = False):
         self._chk(self._L.kmc_forget_source(self._h, (1 if memo else 0) | (2 if history else 0)))

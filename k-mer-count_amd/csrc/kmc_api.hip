@@ -68,6 +68,7 @@ struct kmc_ctx {
     bool sorted_valid = false;
     // walk-kernel workspace
     DevBuf walk_ws;
+    DevBuf vr_reads, vr_cnt, vr_pos;  // pieces of long reads for the walk kernel: [starts | ends], per-read counts and their scan
     DevBuf walk_memo;  // two shared memo snapshots + dense counters, kept across launches (kmc_walk.cuh)
     int memo_parity = 0;  // snapshot slot the next walk launch reads
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
@@ -515,6 +516,34 @@ int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
     return KMC_OK;
 }
 
+// pieces of at most KMC_WALK_MAX_READ bases for a batch with longer reads (kmc_walk.cuh): vr_reads = [starts | ends]
+int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
+    int rc = ensure(c, c->vr_cnt, (size_t)n_reads * sizeof(u64));
+    if (rc) return rc;
+    rc = ensure(c, c->vr_pos, (size_t)n_reads * sizeof(u64));
+    if (rc) return rc;
+    u64 *cnt = (u64*)c->vr_cnt.p, *pos = (u64*)c->vr_pos.p;
+    hipLaunchKernelGGL(kmc_vreads_count_kernel, dim3(grid_for(c, n_reads, 256)), dim3(256), 0, c->stream, d_offsets, n_reads, c->cfg.k, cnt);
+    HIPCHK(c, hipGetLastError());
+    size_t tmp = 0;
+    HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp, cnt, pos, (u64)0, (size_t)n_reads, rocprim::plus<u64>(), c->stream));
+    rc = ensure(c, c->sort_tmp, tmp);
+    if (rc) return rc;
+    HIPCHK(c, rocprim::exclusive_scan(c->sort_tmp.p, tmp, cnt, pos, (u64)0, (size_t)n_reads, rocprim::plus<u64>(), c->stream));
+    u64 last_pos = 0, last_cnt = 0;
+    HIPCHK(c, hipMemcpyAsync(&last_pos, pos + (n_reads - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(&last_cnt, cnt + (n_reads - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const u64 n_v = last_pos + last_cnt;
+    rc = ensure(c, c->vr_reads, (size_t)n_v * 2 * sizeof(u64));
+    if (rc) return rc;
+    u64* vs = (u64*)c->vr_reads.p;
+    hipLaunchKernelGGL(kmc_vreads_fill_kernel, dim3(grid_for(c, n_v, 256)), dim3(256), 0, c->stream, d_offsets, (const u64*)pos, n_reads, n_v, c->cfg.k, vs, vs + n_v);
+    HIPCHK(c, hipGetLastError());
+    *n_v_out = n_v;
+    return KMC_OK;
+}
+
 int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len) {
     if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
     c->sorted_valid = false;
@@ -538,8 +567,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
         bool walk_ok = kmc_walk_supported(c->cfg.k, c->cfg.mode, max_read_len) && n_reads < (1ull << 32);
         if (algo == KMC_ALGO_AUTO && c->walk_overflowed) walk_ok = false;  // high-cardinality input: memo tables do not help
         if (algo == KMC_ALGO_WALK && !walk_ok)
-            return fail(c, KMC_ERR_ARG, "KMC_ALGO_WALK needs k <= %d and reads of at most %d bases (longest here: %llu)",
-                        KMC_WALK_MAX_K, KMC_WALK_MAX_READ, (unsigned long long)max_read_len);
+            return fail(c, KMC_ERR_ARG, "KMC_ALGO_WALK needs contiguous-k mode, k <= %d and fewer than 2^32 reads", KMC_WALK_MAX_K);
         algo = walk_ok ? KMC_ALGO_WALK : KMC_ALGO_STREAM;
     }
     c->st.algo_last = algo;
@@ -592,6 +620,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             }
             return std::min<u64>(take, units_left);
         };
+        double observed_kmers = 0.0;
         auto observe = [&](u64 occ_before, u64 units, u64 kmers_per_unit) -> int {
             int r = poll_and_settle(c);
             if (r) return r;
@@ -600,6 +629,13 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             c->rho_last = rho;
             c->rho_max = std::max(c->rho_max, rho);
             batch_rho_max = std::max(batch_rho_max, rho);
+            // history for later batches from what has been observed of this one so far; the poll after
+            // the batch's last launch (kmc_finalize) replaces it with the whole batch's ratio -- but a
+            // caller that never finalizes this ctx (multi-GPU reduce: the live table is packed and the
+            // ctx reset) must not start every batch without history
+            observed_kmers += (double)units * (double)kmers_per_unit;
+            u64 occ_all = occ_after + c->h_counters[KMC_CTR_SPILL];
+            c->rho_hist = (double)(occ_all > c->b_occ0 ? occ_all - c->b_occ0 : 0) / std::max(observed_kmers, 1.0);
             return KMC_OK;
         };
         u64 stream_from = 0;  // base position from which the stream / sort path takes over
@@ -619,8 +655,21 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 c->memo_parity = 0;
                 c->walk_overflowed = false;
             }
-            const u64 n_tiles = (n_reads + 63) / 64;
-            const u64 kpt = 64 * std::max<u64>(max_read_len, 1);  // k-mers per tile, upper bound
+            // the reads the kernel walks: the batch's own, or pieces of <= KMC_WALK_MAX_READ bases
+            const u64 *d_vs = d_offsets, *d_ve = d_offsets + 1;
+            u64 n_v = n_reads;
+            if (max_read_len > KMC_WALK_MAX_READ) {
+                rc = build_vreads(c, d_offsets, n_reads, &n_v);
+                if (rc) return rc;
+                d_vs = (const u64*)c->vr_reads.p;
+                d_ve = d_vs + n_v;
+            }
+            if (n_v >= (1ull << 32)) return fail(c, KMC_ERR_ARG, "batch too large for one walk pass: %llu read pieces; feed smaller batches", (unsigned long long)n_v);
+            ws_bytes = kmc_walk_workspace_bytes(n_v);
+            rc = ensure(c, c->walk_ws, ws_bytes);
+            if (rc) return rc;
+            const u64 n_tiles = (n_v + 63) / 64;
+            const u64 kpt = 64 * std::min<u64>(std::max<u64>(max_read_len, 1), KMC_WALK_MAX_READ);  // k-mers per tile, upper bound
             u64 done = 0, prev = 0;
             while (done < n_tiles) {
                 u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
@@ -629,12 +678,12 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 if (rc) return fail(c, rc, "walk workspace reset failed");
                 rc = launch_begin(c);  // the event pair brackets the walk kernel alone
                 if (rc) return rc;
-                rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_offsets, n_reads, n_bases,
+                rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
                                      done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), 0);
                 if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
                 rc = launch_end(c);
                 if (rc) return rc;
-                rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_offsets, n_reads, n_bases,
+                rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
                                      done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), 1);
                 if (rc) return fail(c, rc, "scalar/unfold kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
                 c->memo_parity ^= 1;
@@ -647,8 +696,9 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                     if (c->cfg.algo == KMC_ALGO_AUTO && c->walk_overflowed) {
                         // the memo does not help on this input (almost every k-mer is new): hand the rest
                         // of the batch to the sort path
+                        // ... from the end of the last piece walked: the windows ENDING before it are counted
                         u64 pos = 0;
-                        HIPCHK(c, hipMemcpyAsync(&pos, d_offsets + done * 64, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+                        HIPCHK(c, hipMemcpyAsync(&pos, d_ve + (done * 64 - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
                         HIPCHK(c, hipStreamSynchronize(c->stream));
                         stream_from = pos;
                         run_sort = true;
@@ -697,6 +747,22 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     return KMC_OK;
 }
 
+// kernel time of the last batch = sum over its count-kernel launches (host polls between sub-batches
+// are not kernel time).  Only once the batch has finished on the GPU.
+void harvest_timing(kmc_ctx* c) {
+    if (!c->timed || c->lev_used < 2) return;
+    if (hipEventQuery(c->lev[c->lev_used - 1]) != hipSuccess) { (void)hipGetLastError(); return; }
+    float ms = 0.f;
+    double sum = 0.0;
+    for (size_t i = 0; i + 1 < c->lev_used; i += 2) {
+        if (hipEventElapsedTime(&ms, c->lev[i], c->lev[i + 1]) == hipSuccess) sum += ms; else (void)hipGetLastError();
+    }
+    c->st.kernel_ms_last = sum;
+    c->st.kernel_ms_total += sum;
+    c->st.launches_last = (int32_t)(c->lev_used / 2);  // launches in the last batch
+    c->timed = false;
+}
+
 template <typename K>
 int sort_pairs(kmc_ctx* c, const K* kin, K* kout, const u64* vin, u64* vout, u64 n, unsigned bits) {
     size_t tmp = 0;
@@ -743,7 +809,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     if (c->spill_lo) (void)hipFree(c->spill_lo);
     if (c->spill_cnt) (void)hipFree(c->spill_cnt);
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
-                      &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo,
+                      &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo, &c->vr_reads, &c->vr_cnt, &c->vr_pos,
                       &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->s_flags, &c->s_pos, &c->s_head};
     free_runs(c, true);
     for (DevBuf* b : bufs) free_buf(*b);
@@ -1036,19 +1102,7 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
     c->sorted_valid = true;
     c->st.n_distinct = n;
     c->st.n_kmers = n ? n_kmers : 0;
-    float ms = 0.f;
-    if (c->timed) {
-        // kernel time = sum over this batch's count-kernel launches (host polls between
-        // sub-batches are not kernel time); batch_ms brackets everything
-        double sum = 0.0;
-        for (size_t i = 0; i + 1 < c->lev_used; i += 2) {
-            if (hipEventElapsedTime(&ms, c->lev[i], c->lev[i + 1]) == hipSuccess) sum += ms; else (void)hipGetLastError();
-        }
-        c->st.kernel_ms_last = sum;
-        c->st.kernel_ms_total += sum;
-        c->st.launches_last = (int32_t)(c->lev_used / 2);  // launches in the last batch
-        c->timed = false;
-    }
+    harvest_timing(c);
     if (n_distinct) *n_distinct = n;
     if (n_total) *n_total = c->st.n_kmers;
     return KMC_OK;
@@ -1131,8 +1185,17 @@ extern "C" uint64_t kmc_slab_words(const kmc_ctx* c, uint64_t slab_entries) {
 extern "C" int kmc_pack_slab_device(kmc_ctx* c, void* d_slab, uint64_t slab_entries) {
     if (!c || !d_slab || !slab_entries) return c ? fail(c, KMC_ERR_ARG, "kmc_pack_slab_device: null slab or zero capacity") : KMC_ERR_ARG;
     if (((uintptr_t)d_slab & 7) != 0) return fail(c, KMC_ERR_ARG, "d_slab must be 8-byte aligned");
-    if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_pack_slab_device before kmc_finalize");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (!c->sorted_valid) {
+        // not finalized: pack the live table (unsorted) -- the device decides whether it fits
+        GTable g = gtable_of(c, c->tab);
+        const int force = c->runs.empty() ? 0 : 1;  // sorted runs exist only for high-cardinality input: far too large
+        const int grid = grid_for(c, std::min<u64>(slab_entries, KMC_OCC_LIST_CAP), 256);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_pack_slab_live_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64)slab_entries, force, (u64*)d_slab);
+        else hipLaunchKernelGGL(kmc_pack_slab_live_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64)slab_entries, force, (u64*)d_slab);
+        HIPCHK(c, hipGetLastError());
+        return KMC_OK;
+    }
     const u64 n = c->n_sorted;
     const int grid = grid_for(c, std::max<u64>(std::min(n, slab_entries), KMC_SLAB_HEADER), 256);
     if (c->KW == 1) hipLaunchKernelGGL(kmc_pack_slab_kernel<1>, dim3(grid), dim3(256), 0, c->stream, (const u64*)nullptr, c->v_lo, c->v_cnt, n, c->st.n_kmers, slab_entries, (u64*)d_slab);
@@ -1170,6 +1233,16 @@ extern "C" int kmc_merge_slabs_device(kmc_ctx* c, const void* d_slabs, uint32_t 
     return KMC_OK;
 }
 
+extern "C" int kmc_poll(kmc_ctx* c) {
+    if (!c) return KMC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    int rc = poll_and_settle(c);
+    if (rc) return rc;
+    if (c->runs.empty()) c->st.n_kmers = c->h_counters[KMC_CTR_KMERS];  // (the sort path counts at finalize)
+    harvest_timing(c);
+    return KMC_OK;
+}
+
 extern "C" int kmc_forget_source(kmc_ctx* c, int what) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -1188,6 +1261,7 @@ extern "C" int kmc_forget_source(kmc_ctx* c, int what) {
 
 extern "C" int kmc_get_stats(const kmc_ctx* c, kmc_stats* out) {
     if (!c || !out) return KMC_ERR_ARG;
+    harvest_timing(const_cast<kmc_ctx*>(c));  // (kernel_ms_* of a batch that has finished since the last call)
     *out = c->st;
     return KMC_OK;
 }

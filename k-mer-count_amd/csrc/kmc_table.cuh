@@ -123,6 +123,25 @@ __global__ void kmc_pack_slab_kernel(const u64* __restrict__ hi, const u64* __re
     }
 }
 
+// The same slab straight from the LIVE table (no finalize, no sort -- a slab need not be ordered):
+// the first KMC_OCC_LIST_CAP claimed slots are listed in g.occ_list, so a small table is packed
+// without scanning it and without the host knowing its size.  Oversize when the table has more
+// keys than the slab (or than the list), when anything spilled, or when the host says so.
+template <int KW>
+__global__ void kmc_pack_slab_live_kernel(GTable g, u64 entries, int force_oversize, u64* __restrict__ slab) {
+    const u64 n = g.counters[KMC_CTR_OCCUPIED];
+    const bool over = force_oversize || n > entries || n > g.occ_list_cap || g.counters[KMC_CTR_SPILL] != 0 || g.counters[KMC_CTR_ERR] != 0;
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i0 < KMC_SLAB_HEADER) slab[i0] = i0 == 0 ? (over ? KMC_SLAB_OVERSIZE : n) : (i0 == 1 ? g.counters[KMC_CTR_KMERS] : 0ull);
+    if (over) return;
+    for (u64 i = i0; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 slot = g.occ_list[i];
+        slab[KMC_SLAB_HEADER + i] = g.key_lo[slot];
+        slab[KMC_SLAB_HEADER + entries + i] = g.count[slot];
+        if (KW == 2) slab[KMC_SLAB_HEADER + 2 * entries + i] = g.key_hi[slot];
+    }
+}
+
 // The owner's side: of the n_slabs gathered slabs, add every pair whose owner(key) is `my_part`.
 template <int KW>
 __global__ void kmc_merge_slabs_kernel(GTable g, const u64* __restrict__ slabs, u32 n_slabs, u64 slab_words, u64 entries,
@@ -185,9 +204,15 @@ void kmc_small_finalize_kernel(GTable g, u64* __restrict__ out_hi, u64* __restri
         s_ix[i] = (unsigned short)i;
     }
     __syncthreads();
+    // Bitonic network with the pairs laid out block-wise: wave w owns the pairs of elements
+    // [w*B, (w+1)*B), B = N/16.  A pass with j < B only touches a wave's own block, so consecutive such
+    // passes need a wave-level barrier, not __syncthreads -- for N = 4096 that is 68 of the 78 passes
+    // (the kernel took 60 us with a workgroup barrier after every pass).
+    const u32 B = N >= 2048 ? N / 16 : 128;  // elements per wave block (>= 128: one pair per lane)
+    const u32 wv = tid >> 6, lane = tid & 63;
     for (u32 kk = 2; kk <= N; kk <<= 1) {
         for (u32 j = kk >> 1; j > 0; j >>= 1) {
-            for (u32 t = tid; t < N / 2; t += 1024) {
+            for (u32 t = wv * (B / 2) + lane; t < (wv + 1) * (B / 2) && t < N / 2; t += 64) {
                 const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // lower element of the pair
                 const u32 p = i | j;
                 const bool up = (i & kk) == 0;
@@ -201,9 +226,18 @@ void kmc_small_finalize_kernel(GTable g, u64* __restrict__ out_hi, u64* __restri
                     const unsigned short tx = s_ix[i]; s_ix[i] = s_ix[p]; s_ix[p] = tx;
                 }
             }
-            __syncthreads();
+            // the next pass is (kk, j/2), or (2kk, kk) after j == 1
+            const u32 jn = j > 1 ? j >> 1 : kk;
+            if (j >= B || jn >= B) {
+                __syncthreads();
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
         }
     }
+    __syncthreads();
     u64 sum = 0;
     for (u32 i = tid; i < n; i += 1024) {
         const u64 c = g.count[g.occ_list[s_ix[i]]];

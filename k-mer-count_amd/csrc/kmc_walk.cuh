@@ -354,7 +354,7 @@ __device__ __forceinline__ u32 walk_encode16(uint4 v, u32& x0, u32& x1, u32& x2,
 
 template <int KW, bool CANON>
 __global__ __launch_bounds__(KMC_WALK_THREADS)
-void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets, u64 n_reads,
+void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ vstart, const u64* __restrict__ vend, u64 n_reads,
                      int k, u64 tile_begin, u64 tile_end, WalkWs* ws, u32* deferred, const WalkMemoSlot<KW>* memo,
                      WalkMemoSlot<KW>* memo_out, u64* gcnt, GTable g) {
     extern __shared__ __align__(16) unsigned char walk_smem[];
@@ -395,10 +395,13 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         TileGeo t;
         const u64 r = tile * 64 + lane;
         t.have = r < n_reads ? 1u : 0u;
-        t.a = offsets[t.have ? r : n_reads];
-        t.e = offsets[t.have ? r + 1 : n_reads];
+        // read r is bases [vstart[r], vend[r]).  Short-read batches pass offsets and offsets + 1; batches
+        // with reads longer than KMC_WALK_MAX_READ pass the pieces made by kmc_vreads_* (consecutive
+        // pieces of a read overlap by k-1 bases; starts and ends are non-decreasing either way)
+        t.e = vend[t.have ? r : n_reads - 1];
+        t.a = t.have ? vstart[r] : t.e;
         t.A = __shfl(t.a, 0);
-        t.B = __shfl(t.e, 63);  // lanes past the last read hold offsets[n_reads] twice
+        t.B = __shfl(t.e, 63);  // lanes past the last read hold the last end twice
         t.A16 = t.A & ~15ull;
         t.n_pieces = (u32)((t.B - t.A16 + 15) >> 4);
         return t;
@@ -678,7 +681,7 @@ void kmc_walk_unfold_kernel(const WalkMemoSlot<KW>* memo, const u64* gcnt, int k
 
 // One lane per listed read, byte by byte: reads diverted from the walk kernel (non-ACGT bytes).
 template <int KW, bool CANON>
-__global__ void kmc_scalar_reads_kernel(const uint8_t* __restrict__ bases, const u64* __restrict__ offsets,
+__global__ void kmc_scalar_reads_kernel(const uint8_t* __restrict__ bases, const u64* __restrict__ vstart, const u64* __restrict__ vend,
                                         WalkWs* ws, const u32* __restrict__ list, int k, GTable g) {
     const u64 n = ws->n_deferred;
     if (n == 0) return;  // (the common case; the header is cleared by the host only after a non-empty run)
@@ -690,7 +693,7 @@ __global__ void kmc_scalar_reads_kernel(const uint8_t* __restrict__ bases, const
         const u64 r = list[i];
         u64 lo = 0, hi = 0;
         int run = 0;
-        for (u64 p = offsets[r]; p < offsets[r + 1]; ++p) {
+        for (u64 p = vstart[r]; p < vend[r]; ++p) {
             const uint8_t b = bases[p];
             int c = b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : -1;
             if (c < 0) { run = 0; lo = hi = 0; continue; }
@@ -714,7 +717,38 @@ __global__ void kmc_scalar_reads_kernel(const uint8_t* __restrict__ bases, const
 
 // ---- host side ------------------------------------------------------------------------------
 static inline bool kmc_walk_supported(int k, int mode, u64 max_read_len) {
-    return mode == KMC_MODE_CONTIG && k >= 1 && k <= KMC_WALK_MAX_K && max_read_len >= 1 && max_read_len <= KMC_WALK_MAX_READ;
+    return mode == KMC_MODE_CONTIG && k >= 1 && k <= KMC_WALK_MAX_K && max_read_len >= 1;
+}
+
+// ---- reads longer than KMC_WALK_MAX_READ: pieces ("virtual reads") --------------------------------
+// A read of L > MAX bases is walked as ceil((L - (k-1)) / S) pieces of at most MAX bases that start
+// S = MAX - (k-1) bases apart, i.e. consecutive pieces overlap by k-1 bases.  Piece j then holds
+// exactly the windows that END in its last S (or fewer) positions: every window of the read lies in
+// exactly one piece, so walking the pieces as independent reads gives the read's counts, bit for bit.
+__host__ __device__ inline u64 kmc_vreads_of(u64 len, int k) {
+    if (len <= KMC_WALK_MAX_READ) return 1;
+    const u64 S = KMC_WALK_MAX_READ - (u64)(k - 1);
+    return (len - (u64)(k - 1) + S - 1) / S;
+}
+__global__ void kmc_vreads_count_kernel(const u64* __restrict__ offsets, u64 n_reads, int k, u64* __restrict__ cnt) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += (u64)gridDim.x * blockDim.x)
+        cnt[i] = kmc_vreads_of(offsets[i + 1] - offsets[i], k);
+}
+// pos = exclusive scan of cnt; piece v belongs to the read i with pos[i] <= v < pos[i+1] (every read has >= 1 piece)
+__global__ void kmc_vreads_fill_kernel(const u64* __restrict__ offsets, const u64* __restrict__ pos, u64 n_reads, u64 n_v, int k,
+                                       u64* __restrict__ vstart, u64* __restrict__ vend) {
+    const u64 S = KMC_WALK_MAX_READ - (u64)(k - 1);
+    for (u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x; v < n_v; v += (u64)gridDim.x * blockDim.x) {
+        u64 lo = 0, hi = n_reads;  // last i with pos[i] <= v
+        while (hi - lo > 1) {
+            const u64 mid = (lo + hi) >> 1;
+            if (pos[mid] <= v) lo = mid; else hi = mid;
+        }
+        const u64 a = offsets[lo], e = offsets[lo + 1], j = v - pos[lo];
+        const u64 st = a + j * S;
+        vstart[v] = st;
+        vend[v] = (e - st > KMC_WALK_MAX_READ) ? st + KMC_WALK_MAX_READ : e;
+    }
 }
 // memo buffer: two snapshot slots + the dense counter array
 static inline size_t kmc_walk_slot_bytes(int KW) { return KW == 1 ? sizeof(WalkMemoSlot<1>) : sizeof(WalkMemoSlot<2>); }
@@ -722,17 +756,17 @@ static inline size_t kmc_walk_memo_bytes(int, int KW) { return 2 * kmc_walk_slot
 static inline size_t kmc_walk_workspace_bytes(u64 n_reads) { return KMC_WALK_WS_PREFIX + (size_t)(n_reads + 16) * sizeof(u32); }
 
 template <int KW, bool CANON>
-static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const uint8_t* d_bases, const u64* d_offsets,
+static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const uint8_t* d_bases, const u64* d_vstart, const u64* d_vend,
                                      u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, u64* gcnt, void* memo, int parity, GTable g, int phase) {
     const size_t smem = sizeof(WalkLds<KW>);
     static bool attr = false;  // one flag per instantiation
     if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<KW, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
     WalkMemoSlot<KW>* slots = (WalkMemoSlot<KW>*)memo;
     if (phase == 0) {
-        hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_offsets, n_reads, k, tile_begin, tile_end, hdr, list,
+        hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_vstart, d_vend, n_reads, k, tile_begin, tile_end, hdr, list,
                            (const WalkMemoSlot<KW>*)&slots[parity], &slots[parity ^ 1], gcnt, g);
     } else {
-        hipLaunchKernelGGL((kmc_scalar_reads_kernel<KW, CANON>), dim3(n_cu), dim3(256), 0, st, d_bases, d_offsets, hdr, list, k, g);
+        hipLaunchKernelGGL((kmc_scalar_reads_kernel<KW, CANON>), dim3(n_cu), dim3(256), 0, st, d_bases, d_vstart, d_vend, hdr, list, k, g);
         hipLaunchKernelGGL((kmc_walk_unfold_kernel<KW, CANON>), dim3((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE / 256), dim3(256), 0, st,
                            (const WalkMemoSlot<KW>*)&slots[parity], (const u64*)gcnt, k, g);
     }
@@ -745,7 +779,7 @@ static inline int kmc_walk_prepare(hipStream_t st, void* ws) {
     return hipMemsetAsync(ws, 0, KMC_WALK_WS_PREFIX, st) == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
 static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool canon, const uint8_t* d_bases,
-                                  const u64* d_offsets, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, int parity, GTable g, int phase) {
+                                  const u64* d_vstart, const u64* d_vend, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, int parity, GTable g, int phase) {
     if (n_reads >= (1ull << 32) || tile_end <= tile_begin) return KMC_ERR_ARG;
     WalkWs* hdr = (WalkWs*)ws;
     u32* list = (u32*)((char*)ws + KMC_WALK_WS_PREFIX);
@@ -755,11 +789,11 @@ static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool 
     int grid = (int)(want < (u64)n_cu ? want : (u64)n_cu);  // one 160 KB workgroup per CU is resident
     if (grid < 1) grid = 1;
     if (KW == 1) {
-        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
-        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
+        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
+        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
     } else {
-        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
-        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_offsets, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
+        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
+        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
     }
     return hipGetLastError() == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }

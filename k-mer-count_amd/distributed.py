@@ -163,21 +163,23 @@ def _all_gather_slabs(gathered: torch.Tensor, slab: torch.Tensor, group=None):
         gathered.copy_(h)
 
 
-def reduce_tables(local, owner, group=None, slab_entries: int = SLAB_ENTRIES):
+def reduce_tables(local, owner, group=None, slab_entries: int = SLAB_ENTRIES, report_sent: bool = True):
     """The RCCL count-table reduce.  `local`: KmerCounter holding this rank's counts;
     `owner`: a second (reset) KmerCounter on the same GPU that receives the keys this rank owns.
     Afterwards owner.export() is this rank's partition of the global table.
 
     Small tables (at most `slab_entries` keys -- every table of generator-style input) move in ONE
-    fixed-size all-gather of slabs (kmc_pack_slab_device / kmc_merge_slabs_device): no size
-    exchange, and when both ctxs run on torch's current stream no host synchronisation besides the
-    two finalizes.  A rank whose table is larger marks its slab "oversize"; every rank sees that
-    in the gathered headers (stats().n_slabs_skipped of the owner) and those tables then travel by
-    the owner-partitioned all-to-all.  Returns (pairs_sent, pairs_received_or_owned)."""
+    fixed-size all-gather of slabs (kmc_pack_slab_device / kmc_merge_slabs_device).  The slab is
+    packed straight from the live table (a slab need not be sorted), so `local` is not finalized:
+    count -> pack -> all-gather -> merge -> owner.finalize() is one stream of device work with a
+    single host synchronisation at the end when both ctxs run on torch's current stream.  A rank
+    whose table is too large marks its slab "oversize"; every rank sees that in the gathered
+    headers (stats().n_slabs_skipped of the owner) and those tables then travel by the
+    owner-partitioned all-to-all.  Returns (pairs_sent or None, pairs_owned); report_sent=False
+    skips the extra read-back of this rank's own slab header."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = _dev_of(local)
-    n, _ = local.finalize()
     words = local.slab_words(slab_entries)
     slab, gathered = _slab_buffers(words, world, dev)
     local.pack_slab_device(slab.data_ptr(), slab_entries)
@@ -186,11 +188,23 @@ def reduce_tables(local, owner, group=None, slab_entries: int = SLAB_ENTRIES):
     _order(owner, dev)                      # gathered slabs landed before the owner's stream reads them
     owner.merge_slabs_device(gathered.data_ptr(), world, slab_entries, rank, world)
     got, _ = owner.finalize()
-    if owner.stats().n_slabs_skipped == 0:
-        return n, got
+    if local.stats().launches_last != 1:
+        # `local` is never finalized on this path, so its launch planner would not learn what the
+        # batch looked like; while it still splits a batch into several launches let it look (one
+        # small read-back on an idle stream), afterwards nothing
+        local.poll()
+    skipped = owner.stats().n_slabs_skipped
+    sent = None
+    if report_sent or skipped:
+        hdr = int(gathered[rank * words].item())  # this rank's own header as every rank saw it
+        oversize = hdr == -1                      # (KMC_SLAB_OVERSIZE as int64)
+        sent = None if oversize else hdr
+    if not skipped:
+        return sent, got
     # some table did not fit its slab: those ranks send theirs by the partitioned all-to-all
     # (every rank takes part; a rank whose table travelled inline sends nothing)
-    return n, _reduce_tables_a2a(local, owner, group, send=n > slab_entries)
+    n, got = _reduce_tables_a2a(local, owner, group, send=oversize)
+    return (n if oversize else sent), got
 
 
 def _reduce_tables_a2a(local, owner, group=None, send: bool = True):
@@ -221,4 +235,4 @@ def _reduce_tables_a2a(local, owner, group=None, send: bool = True):
         owner.merge_pairs_device(rh.data_ptr() if rh is not None else 0, rl.data_ptr(), rc.data_ptr(), m)
         got += m
     got_total, _ = owner.finalize()
-    return got_total
+    return n, got_total

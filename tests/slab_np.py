@@ -59,6 +59,7 @@ def merge_sorted(his, los, cnts):
 
 
 class _Stats:
+    launches_last = 1
     n_slabs_skipped = 0
     n_distinct = 0
     n_kmers = 0

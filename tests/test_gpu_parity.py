@@ -16,9 +16,10 @@ LR = json.load(open(os.path.join(GOLDEN, "lr_goldens.json")))["cases"]
 
 
 def _algos(kmc, k, max_read_len=None):
-    """Every algorithm that can take this input (WALK: reads <= 416 bases; the others: anything)."""
+    """Every algorithm that can take this input (WALK walks reads longer than 416 bases as
+    overlapping pieces; it needs at least one non-empty read)."""
     a = [kmc.ALGO_STREAM, kmc.ALGO_AUTO, kmc.ALGO_SORT]
-    if k <= 63 and (max_read_len is None or 1 <= max_read_len <= 416):
+    if k <= 63 and (max_read_len is None or max_read_len >= 1):
         a.append(kmc.ALGO_WALK)
     return a
 
@@ -106,6 +107,48 @@ def test_walk_short_reads(kmc, oracle, seed):
             t, st = _count(kmc, bases, offs, k, canonical, kmc.ALGO_WALK)
             assert st.algo_last == kmc.ALGO_WALK
             assert t.equals(want), (seed, k, hi, canonical)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_walk_long_reads_as_pieces(kmc, oracle, seed):
+    """Reads longer than 416 bases go through the walk kernel as pieces that overlap by k-1 bases
+    (kmc_vreads_*): every window lies in exactly one piece, so the table is the oracle's.  Lengths
+    around every piece boundary (416, 416 + S, ...), one read of 150 k bases, short and empty reads in
+    between, non-ACGT bytes (pieces diverted to the scalar kernel), low and high cardinality."""
+    rng = np.random.default_rng(700 + seed)
+    for k in (1, 5, 31, 32, 63):
+        S = 416 - (k - 1)
+        lens = [417, 416, 0, 416 + S, 416 + S + 1, 415, 2 * S + k - 1, 2 * S + k, 3, 150_000, 1000, k - 1, k, 5000]
+        lens += [int(x) for x in rng.integers(0, 3000, 40)]
+        offs = np.zeros(len(lens) + 1, np.uint64)
+        offs[1:] = np.cumsum(lens)
+        n = int(offs[-1])
+        if seed % 2 == 0:  # low cardinality: lines of 50 bases from a pool of 6
+            pool = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (6, 50))]
+            bases = pool[rng.integers(0, 6, n // 50 + 2)].reshape(-1)[:n].copy()
+        else:
+            bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, n)].copy()
+        if seed >= 2:
+            bad = rng.random(n) < 0.0005
+            bases[bad] = ord("N")
+        for canonical in (True, False):
+            want = oracle.count_kmers(bases, offs, k, canonical)
+            t, st = _count(kmc, bases, offs, k, canonical, kmc.ALGO_WALK)
+            assert st.algo_last == kmc.ALGO_WALK
+            assert t.equals(want), (seed, k, canonical)
+            t, st = _count(kmc, bases, offs, k, canonical, kmc.ALGO_AUTO)
+            assert t.equals(want), (seed, k, canonical, "auto", st.algo_last)
+    # device-resident batch with max_read_len unknown (computed on the device), twice (additivity)
+    torch = pytest.importorskip("torch")
+    d_b = torch.from_numpy(np.concatenate([bases, np.zeros(64, np.uint8)])).cuda()
+    d_o = torch.from_numpy(offs.astype(np.int64)).cuda()
+    torch.cuda.synchronize()
+    with kmc.KmerCounter(k=63, algo=kmc.ALGO_WALK) as kc:
+        want = oracle.count_kmers(bases, offs, 63, True)
+        kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), len(lens), n, 0)
+        kc.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), len(lens), n, 0)
+        t = kc.export()
+        assert np.array_equal(t.key_lo, want.key_lo) and np.array_equal(t.key_hi, want.key_hi) and np.array_equal(t.count, want.count * 2)
 
 
 def test_low_complexity_and_palindromes(kmc, oracle):
@@ -359,6 +402,26 @@ def test_slab_pack_and_merge_kernels(kmc, oracle):
             got = slab_np.unpack(host[i * words:(i + 1) * words], kw, E)
             assert got is not None and int(host[i * words]) == t.n_distinct and int(host[i * words + 1]) == t.n_total
             assert np.array_equal(got[0], t.key_hi) and np.array_equal(got[1], t.key_lo) and np.array_equal(got[2], t.count)
+        # the same slabs straight from the live (not finalized, unsorted) tables
+        live = torch.full((3 * words,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        fresh = []
+        for i in range(3):
+            sb = bases[int(offs[cuts[i]]):int(offs[cuts[i + 1]])]
+            so = offs[cuts[i]:cuts[i + 1] + 1] - offs[cuts[i]]
+            kc = kmc.KmerCounter(k=k)
+            kc.add_batch(sb, so)
+            kc.pack_slab_device(live.data_ptr() + 8 * words * i, E)  # no finalize first
+            fresh.append(kc)
+        for kc in fresh:
+            kc.finalize()
+            kc.close()
+        hl = live.cpu().numpy().view(np.uint64)
+        for i, t in enumerate(shards):
+            got = slab_np.unpack(hl[i * words:(i + 1) * words], kw, E)
+            assert got is not None and int(hl[i * words]) == t.n_distinct and int(hl[i * words + 1]) == t.n_total
+            h2, l2, c2 = slab_np.merge_sorted([got[0]], [got[1]], [got[2]])
+            assert np.array_equal(h2, t.key_hi) and np.array_equal(l2, t.key_lo) and np.array_equal(c2, t.count)
         want = oracle.count_kmers(bases, offs, k, True)
         owned = []
         for part in range(3):
@@ -388,6 +451,16 @@ def test_slab_pack_and_merge_kernels(kmc, oracle):
             assert t.n_total == sum(sh.n_total for sh in inline)
         for kc in ctxs:
             kc.close()
+    # a live table with more keys than the slab (or than the claimed-slot list) is oversize
+    rng = np.random.default_rng(9)
+    rb, ro = _random_reads(rng, 400, 100, 300)
+    with kmc.KmerCounter(k=31) as kc:
+        kc.add_batch(rb, ro)
+        sl = torch.zeros(kc.slab_words(1 << 16), dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        kc.pack_slab_device(sl.data_ptr(), 1 << 16)
+        kc.finalize()
+        assert int(sl[0].item()) == -1
 
 
 def test_rccl_reduce_small_tables_on_torch_stream(kmc, oracle):
@@ -468,6 +541,59 @@ def test_reference_mode_cli_and_errors(kmc, oracle, tmp_path):
     with kmc.KmerCounter(mode=kmc.MODE_LR) as kc:
         kc.add_batch(bases, offs)
         assert kc.export().equals(oracle.count_lr(bases, offs))
+
+
+def test_count_file_pipeline_chunks(kmc, oracle, tmp_path, monkeypatch):
+    """kmc_count_file = streaming reader + pinned double buffers + upload of the reader's pieces to
+    their dense place + one batch per chunk.  Every chunking gives the oracle's table: sample.fasta
+    cut into ~90 chunks (k = 5, 31, 63 and the reference's LR mode against its golden digest), and a
+    60 MB generator-style file in 7 multi-threaded chunks."""
+    import subprocess
+    from conftest import ROOT
+    bases, offs = oracle.parse_fasta(SAMPLE)
+    for cb in ("1000", "30000", ""):
+        if cb:
+            monkeypatch.setenv("KMC_INGEST_CHUNK_BYTES", cb)
+        else:
+            monkeypatch.delenv("KMC_INGEST_CHUNK_BYTES", raising=False)
+        for k in (5, 31, 63):
+            want = oracle.count_kmers(bases, offs, k, True)
+            with kmc.KmerCounter(k=k) as kc:
+                nd, nt = kc.count_file(SAMPLE)
+                assert (nd, nt) == (want.n_distinct, want.n_total)
+                assert kc.export().equals(want), (cb, k)
+                assert kc.stats().n_batches == (1 if not cb else -(-87492 // int(cb))) or kc.stats().n_batches > 1
+        with kmc.KmerCounter(mode=kmc.MODE_LR) as kc:
+            kc.count_file(SAMPLE)
+            t = kc.export()
+            assert t.n_distinct == LR["G-full"]["distinct"] and t.digest(expand=True) == LR["G-full"]["sha256"], cb
+    # the reference aborts on a non-ACGT character (main.rs:23), whichever chunk holds it
+    monkeypatch.setenv("KMC_INGEST_CHUNK_BYTES", "200")
+    bad = tmp_path / "bad.fasta"
+    bad.write_bytes(b">r0\n" + b"ACGT" * 40 + b"\n>r1\n" + b"ACGT" * 30 + b"N" + b"ACGT" * 30 + b"\n")
+    with kmc.KmerCounter(mode=kmc.MODE_LR) as kc:
+        with pytest.raises(kmc.KmcError) as e:
+            kc.count_file(str(bad))
+        assert e.value.status == kmc.ERR_ALPHABET
+    with kmc.KmerCounter(k=31) as kc:  # count-table mode skips windows with the N instead
+        b2, o2 = oracle.parse_fasta(str(bad))
+        kc.count_file(str(bad))
+        assert kc.export().equals(oracle.count_kmers(b2, o2, 31, True))
+    with kmc.KmerCounter(k=31) as kc:
+        with pytest.raises(kmc.KmcError) as e:
+            kc.count_file(str(tmp_path / "missing.fasta"))
+        assert e.value.status == kmc.ERR_IO
+    # multi-threaded chunks
+    exe = os.path.join(ROOT, "bin", "kmc-genfasta")
+    p = tmp_path / "big.fasta"
+    with open(p, "wb") as f:
+        subprocess.run([exe, "--bytes", "60000000", "--seed", "13"], stdout=f, check=True)
+    b3, o3 = oracle.parse_fasta(str(p))
+    want = oracle.count_kmers(b3, o3, 31, True)
+    monkeypatch.setenv("KMC_INGEST_CHUNK_BYTES", "9000000")
+    with kmc.KmerCounter(k=31) as kc:
+        kc.count_file(str(p))
+        assert kc.export().equals(want) and kc.stats().n_batches == 7
 
 
 def test_walk_repeatability_stress(kmc, oracle):

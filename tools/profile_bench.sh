@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 export TMPDIR=/tmp
-args="--steps 5 --warmup 6 --no-cpu-baseline $*"
+args="--steps 5 --warmup 6 --no-cpu-baseline --no-cold $*"
 cd $root
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $args > $out/trace.log 2>&1
 echo "trace rc=$?"
