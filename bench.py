@@ -197,6 +197,37 @@ def main():
                "gpu_bit_exact_on_sample": exact}
         if not exact:
             raise SystemExit("GPU table differs from the CPU oracle on the baseline sample")
+        # SURVEY.md 8d's other two CPU views (reported next to the baseline, not instead of it):
+        # B1 = the reference's algorithm SHAPE on contiguous k (materialise every window as a string,
+        # comparison sort, run-length: main.rs:78-79,87), 1 core like the reference;
+        # B2 on all host cores = the same hash-map counter, one record shard per thread (tables not merged).
+        extra = {}
+        nb1 = min(20_000, n_rec)
+        tb = time.perf_counter()
+        w1 = oracle_py.count_kmers_strings(hb[:nb1 * read_len], ho[:nb1 + 1], k, canonical=not args.forward)
+        dt1 = time.perf_counter() - tb
+        extra["b1_reference_shape"] = {"value": round(w1.n_total / dt1, 1), "unit": "k-mers/s", "cores": 1, "kind": "port",
+                                       "sample": f"first {nb1} records; every window materialised as a string, qsort, run-length; {dt1:.2f} s"}
+        import threading
+        T = max(1, min(os.cpu_count() or 1, 16))
+        per = max(1, min(600_000, ns // T))
+        totals = [0] * T
+
+        def shard(i):
+            b0 = i * per * read_len
+            o = (ho[i * per:(i + 1) * per + 1] - ho[i * per]).copy()
+            totals[i] = oracle_py.count_kmers(hb[b0:b0 + per * read_len], o, k, canonical=not args.forward, method=1).n_total
+
+        th = [threading.Thread(target=shard, args=(i,)) for i in range(T)]
+        tb = time.perf_counter()
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        dt2 = time.perf_counter() - tb
+        extra["b2_all_cores"] = {"value": round(sum(totals) / dt2, 1), "unit": "k-mers/s", "cores": T, "kind": "port",
+                                 "sample": f"{T} threads x {per} records of the same workload, one hash-map table per thread (not merged); {dt2:.2f} s"}
+        cpu["other_views"] = extra
 
     if rank == 0:
         total_kmers = n_kmers * world * args.steps

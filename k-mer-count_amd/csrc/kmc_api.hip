@@ -71,6 +71,7 @@ struct kmc_ctx {
     DevBuf vr_reads, vr_cnt, vr_pos;  // pieces of long reads for the walk kernel: [starts | ends], per-read counts and their scan
     DevBuf walk_memo;  // two shared memo snapshots + dense counters, kept across launches (kmc_walk.cuh)
     int memo_parity = 0;  // snapshot slot the next walk launch reads
+    bool walk_ws_clean = false;  // workspace header + dense counters are zero (left so by kmc_walk_unfold_kernel)
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
     DevBuf s_lo[2], s_hi[2], s_flags, s_pos, s_head;
     struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0, cap = 0; };
@@ -643,9 +644,6 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
         bool run_sort = (algo == KMC_ALGO_SORT);
         const bool is_auto = c->cfg.algo == KMC_ALGO_AUTO;
         if (algo == KMC_ALGO_WALK) {
-            size_t ws_bytes = kmc_walk_workspace_bytes(n_reads);
-            rc = ensure(c, c->walk_ws, ws_bytes);
-            if (rc) return rc;
             if (!c->walk_memo.p || c->walk_overflowed) {
                 // (re)start from an empty memo: first use, or the last batch overflowed it (its entries
                 // were not representative; keeping them would only hold the tables full)
@@ -665,17 +663,23 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 d_ve = d_vs + n_v;
             }
             if (n_v >= (1ull << 32)) return fail(c, KMC_ERR_ARG, "batch too large for one walk pass: %llu read pieces; feed smaller batches", (unsigned long long)n_v);
-            ws_bytes = kmc_walk_workspace_bytes(n_v);
-            rc = ensure(c, c->walk_ws, ws_bytes);
-            if (rc) return rc;
+            {
+                void* before = c->walk_ws.p;
+                rc = ensure(c, c->walk_ws, kmc_walk_workspace_bytes(n_v));
+                if (rc) return rc;
+                if (c->walk_ws.p != before) c->walk_ws_clean = false;  // fresh memory: the host clears header + counters once
+            }
             const u64 n_tiles = (n_v + 63) / 64;
             const u64 kpt = 64 * std::min<u64>(std::max<u64>(max_read_len, 1), KMC_WALK_MAX_READ);  // k-mers per tile, upper bound
             u64 done = 0, prev = 0;
             while (done < n_tiles) {
                 u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
                 u64 take = plan(n_tiles - done, kpt, prev);
-                rc = kmc_walk_prepare(c->stream, c->walk_ws.p);
-                if (rc) return fail(c, rc, "walk workspace reset failed");
+                if (!c->walk_ws_clean) {  // (normally the unfold kernel of the previous launch left it clean)
+                    rc = kmc_walk_prepare(c->stream, c->walk_ws.p);
+                    if (rc) return fail(c, rc, "walk workspace reset failed");
+                }
+                c->walk_ws_clean = false;
                 rc = launch_begin(c);  // the event pair brackets the walk kernel alone
                 if (rc) return rc;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
@@ -686,6 +690,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
                                      done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), 1);
                 if (rc) return fail(c, rc, "scalar/unfold kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+                c->walk_ws_clean = true;
                 c->memo_parity ^= 1;
                 c->pending = true;
                 done += take;

@@ -171,81 +171,144 @@ __global__ void kmc_sum_kernel(const u64* cnt, u64 n, u64* counters) {
 }
 
 // Fast finalize for small tables (n <= KMC_OCC_LIST_CAP claimed slots, listed in g.occ_list): ONE
-// workgroup gathers the keys, sorts them in LDS (bitonic network, ascending by (hi, lo)) and writes
-// the sorted view and the sum of counts -- instead of scanning the whole table, three library sort
+// workgroup gathers the keys, sorts them (bitonic network, ascending by (hi, lo)) and writes the
+// sorted view and the sum of counts -- instead of scanning the whole table, three library sort
 // launches and a gather.  This is the GPU form of the reference's final ordering step
 // (k-mer-count/src/main.rs:87) for the common case of a few thousand distinct keys.
 // It is launched speculatively right behind the count kernels: it reads the occupancy on the device
 // and gives up (FASTFIN = 0) unless the table is small and nothing spilled, so kmc_finalize needs a
 // single host synchronisation.
+//
+// The network runs in REGISTERS: N = 1024 * E elements (E = 1, 2, 4, 8), thread t holds the elements
+// with sorted positions t*E .. t*E+E-1.  A compare-exchange at distance j is a register swap inside
+// the thread (j < E), a wave shuffle with lane ^ (j/E) (j < 64 E), and only for the widest distances
+// (j >= 64 E: 10 of the 78 passes at N = 4096) an exchange through LDS with a workgroup barrier.
+// (The first version kept the elements in LDS with a barrier after every pass: 56-60 us for 3,350
+// keys; making 68 of its passes wave-local did not help -- it was bound by LDS instruction issue on
+// one CU, not by the barriers.)
+template <int KW>
+__device__ __forceinline__ bool sf_gt(u64 ahi, u64 alo, u64 bhi, u64 blo) {
+    return KW == 2 ? (ahi > bhi || (ahi == bhi && alo > blo)) : alo > blo;
+}
+
+template <int KW, int E, int J>
+__device__ __forceinline__ void sf_in_thread(u64 (&lo)[E], u64 (&hi)[E], u32 (&ix)[E], u32 tbase, u32 kk) {
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        if ((e & J) == 0 && (e | J) < E) {
+            const int p = e | J;
+            const bool up = ((tbase + e) & kk) == 0;
+            const bool gt = sf_gt<KW>(hi[e], lo[e], hi[p], lo[p]);
+            if (gt == up) {
+                u64 t = lo[e]; lo[e] = lo[p]; lo[p] = t;
+                if (KW == 2) { t = hi[e]; hi[e] = hi[p]; hi[p] = t; }
+                u32 x = ix[e]; ix[e] = ix[p]; ix[p] = x;
+            }
+        }
+    }
+}
+
+template <int KW, int E>
+__device__ __forceinline__ void small_finalize_sort(const GTable& g, u64 n, u64* __restrict__ out_hi, u64* __restrict__ out_lo,
+                                                    u64* __restrict__ out_cnt, u64* s_lo, u64* s_hi, unsigned short* s_ix) {
+    const u32 tid = threadIdx.x, lane = tid & 63;
+    constexpr u32 N = 1024u * E;
+    u64 lo[E], hi[E];
+    u32 ix[E];
+    // initial placement is arbitrary (we are sorting): slot e of thread t takes list entry e*1024 + t (coalesced)
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u32 i = (u32)e * 1024u + tid;
+        ix[e] = i;
+        if (i < n) {
+            const u64 slot = g.occ_list[i];
+            lo[e] = g.key_lo[slot];
+            hi[e] = KW == 2 ? g.key_hi[slot] : 0ull;
+        } else {  // padding sorts last (valid keys never have the top bits set)
+            lo[e] = ~0ull;
+            hi[e] = KW == 2 ? ~0ull : 0ull;
+        }
+    }
+    const u32 tbase = tid * E;
+    for (u32 kk = 2; kk <= N; kk <<= 1) {
+        for (u32 j = kk >> 1; j > 0; j >>= 1) {
+            if (j >= 64u * E) {
+                // partner lives in another wave: through LDS, element (t, e) at e*1024 + t (conflict-free)
+                const u32 pt = tid ^ (j / E);
+                __syncthreads();  // (the previous LDS pass's reads are done)
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    s_lo[e * 1024 + tid] = lo[e];
+                    if (KW == 2) s_hi[e * 1024 + tid] = hi[e];
+                    s_ix[e * 1024 + tid] = (unsigned short)ix[e];
+                }
+                __syncthreads();
+                const bool lower = (tid & (j / E)) == 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const u64 plo = s_lo[e * 1024 + pt];
+                    const u64 phi = KW == 2 ? s_hi[e * 1024 + pt] : 0ull;
+                    const u32 pix = s_ix[e * 1024 + pt];
+                    const bool up = ((tbase + e) & kk) == 0;
+                    const bool want_min = lower == up;
+                    const bool take = want_min ? sf_gt<KW>(hi[e], lo[e], phi, plo) : sf_gt<KW>(phi, plo, hi[e], lo[e]);
+                    if (take) { lo[e] = plo; hi[e] = phi; ix[e] = pix; }
+                }
+            } else if (j >= (u32)E) {
+                const int m = (int)(j / E);  // lane xor mask, < 64
+                const bool lower = (lane & (u32)m) == 0;
+#pragma unroll
+                for (int e = 0; e < E; ++e) {
+                    const u64 plo = __shfl_xor(lo[e], m);
+                    const u64 phi = KW == 2 ? __shfl_xor(hi[e], m) : 0ull;
+                    const u32 pix = __shfl_xor(ix[e], m);
+                    const bool up = ((tbase + e) & kk) == 0;
+                    const bool want_min = lower == up;
+                    const bool take = want_min ? sf_gt<KW>(hi[e], lo[e], phi, plo) : sf_gt<KW>(phi, plo, hi[e], lo[e]);
+                    if (take) { lo[e] = plo; hi[e] = phi; ix[e] = pix; }
+                }
+            } else if (j == 4) {
+                sf_in_thread<KW, E, (E > 4 ? 4 : 1)>(lo, hi, ix, tbase, kk);
+            } else if (j == 2) {
+                sf_in_thread<KW, E, (E > 2 ? 2 : 1)>(lo, hi, ix, tbase, kk);
+            } else {
+                sf_in_thread<KW, E, 1>(lo, hi, ix, tbase, kk);
+            }
+        }
+    }
+    u64 sum = 0;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const u32 i = tbase + e;  // sorted position
+        if (i < n) {
+            const u64 c = g.count[g.occ_list[ix[e]]];
+            out_lo[i] = lo[e];
+            if (KW == 2) out_hi[i] = hi[e];
+            out_cnt[i] = c;
+            sum += c;
+        }
+    }
+    sum = wave_sum_u64(sum);
+    if (lane == 0 && sum) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_SUM2], sum);
+}
+
 template <int KW>
 __global__ __launch_bounds__(1024)
 void kmc_small_finalize_kernel(GTable g, u64* __restrict__ out_hi, u64* __restrict__ out_lo, u64* __restrict__ out_cnt) {
+    // exchange buffers of the widest passes (only E >= 2 has any: j >= 64 E needs N >= 128 E)
     __shared__ u64 s_lo[KMC_OCC_LIST_CAP];
     __shared__ u64 s_hi[KW == 2 ? KMC_OCC_LIST_CAP : 1];
     __shared__ unsigned short s_ix[KMC_OCC_LIST_CAP];
     const int tid = threadIdx.x;
     const u64 n = g.counters[KMC_CTR_OCCUPIED];
     const bool ok = n > 0 && n <= KMC_OCC_LIST_CAP && g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0;
+    __syncthreads();  // (every thread has read the counters before thread 0 rewrites two of them)
     if (tid == 0) { g.counters[KMC_CTR_FASTFIN] = ok ? 1 : 0; g.counters[KMC_CTR_SUM2] = 0; }
     if (!ok) return;
+    __threadfence();
     __syncthreads();
-    u32 N = 1;
-    while (N < n) N <<= 1;  // padded to a power of two with all-ones keys (sort last)
-    for (u32 i = tid; i < N; i += 1024) {
-        if (i < n) {
-            const u64 slot = g.occ_list[i];
-            s_lo[i] = g.key_lo[slot];
-            if (KW == 2) s_hi[i] = g.key_hi[slot];
-        } else {
-            s_lo[i] = ~0ull;
-            if (KW == 2) s_hi[i] = ~0ull;
-        }
-        s_ix[i] = (unsigned short)i;
-    }
-    __syncthreads();
-    // Bitonic network with the pairs laid out block-wise: wave w owns the pairs of elements
-    // [w*B, (w+1)*B), B = N/16.  A pass with j < B only touches a wave's own block, so consecutive such
-    // passes need a wave-level barrier, not __syncthreads -- for N = 4096 that is 68 of the 78 passes
-    // (the kernel took 60 us with a workgroup barrier after every pass).
-    const u32 B = N >= 2048 ? N / 16 : 128;  // elements per wave block (>= 128: one pair per lane)
-    const u32 wv = tid >> 6, lane = tid & 63;
-    for (u32 kk = 2; kk <= N; kk <<= 1) {
-        for (u32 j = kk >> 1; j > 0; j >>= 1) {
-            for (u32 t = wv * (B / 2) + lane; t < (wv + 1) * (B / 2) && t < N / 2; t += 64) {
-                const u32 i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // lower element of the pair
-                const u32 p = i | j;
-                const bool up = (i & kk) == 0;
-                const u64 alo = s_lo[i], blo = s_lo[p];
-                bool gt;
-                if (KW == 2) { const u64 ahi = s_hi[i], bhi = s_hi[p]; gt = ahi > bhi || (ahi == bhi && alo > blo); }
-                else gt = alo > blo;
-                if (gt == up) {
-                    s_lo[i] = blo; s_lo[p] = alo;
-                    if (KW == 2) { const u64 th = s_hi[i]; s_hi[i] = s_hi[p]; s_hi[p] = th; }
-                    const unsigned short tx = s_ix[i]; s_ix[i] = s_ix[p]; s_ix[p] = tx;
-                }
-            }
-            // the next pass is (kk, j/2), or (2kk, kk) after j == 1
-            const u32 jn = j > 1 ? j >> 1 : kk;
-            if (j >= B || jn >= B) {
-                __syncthreads();
-            } else {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-        }
-    }
-    __syncthreads();
-    u64 sum = 0;
-    for (u32 i = tid; i < n; i += 1024) {
-        const u64 c = g.count[g.occ_list[s_ix[i]]];
-        out_lo[i] = s_lo[i];
-        if (KW == 2) out_hi[i] = s_hi[i];
-        out_cnt[i] = c;
-        sum += c;
-    }
-    sum = wave_sum_u64(sum);
-    if ((tid & 63) == 0 && sum) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_SUM2], sum);
+    if (n <= 1024) small_finalize_sort<KW, 1>(g, n, out_hi, out_lo, out_cnt, s_lo, s_hi, s_ix);
+    else if (n <= 2048) small_finalize_sort<KW, 2>(g, n, out_hi, out_lo, out_cnt, s_lo, s_hi, s_ix);
+    else if (n <= 4096) small_finalize_sort<KW, 4>(g, n, out_hi, out_lo, out_cnt, s_lo, s_hi, s_ix);
+    else small_finalize_sort<KW, 8>(g, n, out_hi, out_lo, out_cnt, s_lo, s_hi, s_ix);
 }

@@ -78,7 +78,8 @@ struct WalkLds {
 };
 
 // workspace (device): [WalkWs header | gcnt[NCAP+ECAP] dense snapshot counters | u32 deferred read
-// indices]; one memset before every launch clears the header and the counters
+// indices]; header and counters are zero before every launch: cleared once by the host when the
+// buffer is (re)allocated, afterwards by kmc_walk_unfold_kernel, their last reader
 struct WalkWs {
     unsigned long long n_deferred;
     unsigned long long pad[7];
@@ -650,7 +651,10 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
 // k-mer counts, once per launch (gcnt is cleared by kmc_walk_prepare before the next launch).
 template <int KW, bool CANON>
 __global__ __launch_bounds__(256)
-void kmc_walk_unfold_kernel(const WalkMemoSlot<KW>* memo, const u64* gcnt, int k, GTable g) {
+void kmc_walk_unfold_kernel(const WalkMemoSlot<KW>* memo, u64* gcnt, WalkWs* ws, int k, GTable g) {
+    // the scalar kernel (queued before this one) was the last reader of the deferred-read counter:
+    // leave the workspace clean for the next launch (no memset per launch)
+    if (blockIdx.x == 0 && threadIdx.x == 0) ws->n_deferred = 0;
     if (memo->tag != (KMC_WALK_MEMO_TAG | (u64)k)) return;  // the launch ran without a snapshot: gcnt untouched
     const u32 tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     const int kb = 2 * k;
@@ -677,6 +681,10 @@ void kmc_walk_unfold_kernel(const WalkMemoSlot<KW>* memo, const u64* gcnt, int k
             if (depth >= (u32)k) walk_gadd<KW, CANON>(g, ctx, k, cnt);
         }
     }
+    // every entry is read by 16 consecutive threads of ONE block (the grid covers the item space exactly
+    // once): after the block's reads, clear its entries for the next launch
+    __syncthreads();
+    if (threadIdx.x < 256 / KMC_WALK_STRIDE) gcnt[blockIdx.x * (256 / KMC_WALK_STRIDE) + threadIdx.x] = 0;
 }
 
 // One lane per listed read, byte by byte: reads diverted from the walk kernel (non-ACGT bytes).
@@ -767,8 +775,9 @@ static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const u
                            (const WalkMemoSlot<KW>*)&slots[parity], &slots[parity ^ 1], gcnt, g);
     } else {
         hipLaunchKernelGGL((kmc_scalar_reads_kernel<KW, CANON>), dim3(n_cu), dim3(256), 0, st, d_bases, d_vstart, d_vend, hdr, list, k, g);
+        static_assert(((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE) % 256 == 0 && 256 % KMC_WALK_STRIDE == 0, "unfold grid must cover the items exactly");
         hipLaunchKernelGGL((kmc_walk_unfold_kernel<KW, CANON>), dim3((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE / 256), dim3(256), 0, st,
-                           (const WalkMemoSlot<KW>*)&slots[parity], (const u64*)gcnt, k, g);
+                           (const WalkMemoSlot<KW>*)&slots[parity], gcnt, hdr, k, g);
     }
 }
 

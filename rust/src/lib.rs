@@ -33,6 +33,35 @@ extern "C" {
     pub fn kmc_finalize(ctx: *mut KmcCtx, n_distinct: *mut u64, n_total: *mut u64) -> c_int;
     pub fn kmc_export(ctx: *mut KmcCtx, key_hi: *mut u64, key_lo: *mut u64, count: *mut u64, cap: u64) -> c_int;
     pub fn kmc_decode_key(key_hi: u64, key_lo: u64, klen: c_int, out: *mut c_char);
+    pub fn kmc_count_file(ctx: *mut KmcCtx, path: *const c_char, n_distinct: *mut u64, n_total: *mut u64) -> c_int;
+    pub fn kmc_add_batch_device(ctx: *mut KmcCtx, d_bases: *const c_void, d_offsets: *const c_void, n_reads: u64, n_bases: u64, max_read_len: u64) -> c_int;
+    pub fn kmc_poll(ctx: *mut KmcCtx) -> c_int;
+    pub fn kmc_forget_source(ctx: *mut KmcCtx, what: c_int) -> c_int;
+    // multi-GPU reduce (one process per GPU; the collective itself is the host program's, e.g. RCCL)
+    pub fn kmc_slab_words(ctx: *const KmcCtx, slab_entries: u64) -> u64;
+    pub fn kmc_pack_slab_device(ctx: *mut KmcCtx, d_slab: *mut c_void, slab_entries: u64) -> c_int;
+    pub fn kmc_merge_slabs_device(ctx: *mut KmcCtx, d_slabs: *const c_void, n_slabs: u32, slab_entries: u64, my_part: u32, n_parts: u32) -> c_int;
+    pub fn kmc_partition_device(ctx: *mut KmcCtx, n_parts: u32, part_begin: *mut u64, d_key_hi: *mut *const c_void,
+                                d_key_lo: *mut *const c_void, d_count: *mut *const c_void) -> c_int;
+    pub fn kmc_merge_pairs_device(ctx: *mut KmcCtx, d_key_hi: *const c_void, d_key_lo: *const c_void, d_count: *const c_void, n_pairs: u64) -> c_int;
+    // streaming host reader (chunks end at record boundaries; buffers owned by the stream)
+    pub fn kmc_fasta_stream_open(path: *const c_char, chunk_bytes: u64, out: *mut *mut KmcFastaStream, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn kmc_fasta_stream_next(s: *mut KmcFastaStream, out: *mut KmcReads, eof: *mut c_int, errbuf: *mut c_char, errbuf_len: usize) -> c_int;
+    pub fn kmc_fasta_stream_close(s: *mut KmcFastaStream);
+}
+
+#[repr(C)]
+pub struct KmcFastaStream {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct KmcReads {
+    pub bases: *mut u8,
+    pub offsets: *mut u64,
+    pub n_reads: u64,
+    pub n_bases: u64,
+    pub max_read_len: u64,
 }
 
 /// One counting context on one GPU.  Not `Sync`: a ctx is single-threaded (kmc.h).
@@ -78,6 +107,15 @@ impl Counter {
     pub fn add_batch(&mut self, bases: &[u8], offsets: &[u64]) -> Result<(), KmcError> {
         let rc = unsafe { kmc_add_batch(self.ctx, bases.as_ptr(), offsets.as_ptr(), (offsets.len() - 1) as u64) };
         self.check(rc)
+    }
+
+    /// FASTA path in: the library's own pipelined reader (parse on the host cores overlapped with
+    /// upload and counting) instead of `bio`'s record loop (main.rs:44-46,58-62).
+    pub fn count_file(&mut self, path: &str) -> Result<(u64, u64), KmcError> {
+        let c = std::ffi::CString::new(path).map_err(|_| KmcError(-1, "path contains NUL".into()))?;
+        let (mut nd, mut nt) = (0u64, 0u64);
+        self.check(unsafe { kmc_count_file(self.ctx, c.as_ptr(), &mut nd, &mut nt) })?;
+        Ok((nd, nt))
     }
 
     /// Sorted table: (key as ASCII, count), ascending == the order of `lr_chunk.sort()` (main.rs:87).

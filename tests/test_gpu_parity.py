@@ -109,6 +109,26 @@ def test_walk_short_reads(kmc, oracle, seed):
             assert t.equals(want), (seed, k, hi, canonical)
 
 
+def test_walk_round_boundaries(kmc, oracle):
+    """The walk kernel's load rounds are 320 sixteen-byte pieces: tiles whose byte range is exactly
+    1, 2, 3, 4, 5 rounds (64 reads of 80, 160, 240, 320, 400 bases), one piece more or less, shifted
+    off 16-byte alignment by a leading odd read, plus whole tiles of empty reads in the middle and at
+    the end of the batch (a tile with no pieces at all)."""
+    rng = np.random.default_rng(31)
+    pool = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (5, 16))]
+    for read_len in (80, 160, 240, 320, 400, 79, 81, 319, 321, 399, 401, 16, 15, 1):
+        for lead in (0, 7):
+            lens = ([lead] if lead else []) + [read_len] * 200 + [0] * 130 + [read_len] * 70 + [0] * 200
+            offs = np.zeros(len(lens) + 1, np.uint64)
+            offs[1:] = np.cumsum(lens)
+            n = int(offs[-1])
+            bases = pool[rng.integers(0, 5, n // 16 + 2)].reshape(-1)[:n].copy()
+            for k in (5, 31):
+                want = oracle.count_kmers(bases, offs, k, True)
+                t, st = _count(kmc, bases, offs, k, True, kmc.ALGO_WALK)
+                assert st.algo_last == kmc.ALGO_WALK and t.equals(want), (read_len, lead, k)
+
+
 @pytest.mark.parametrize("seed", range(4))
 def test_walk_long_reads_as_pieces(kmc, oracle, seed):
     """Reads longer than 416 bases go through the walk kernel as pieces that overlap by k-1 bases
