@@ -57,6 +57,7 @@ struct kmc_ctx {
     u64* d_counters = nullptr;      // KMC_CTR_N u64
     u64* h_counters = nullptr;      // pinned mirror
     u64* occ_list = nullptr;        // first KMC_OCC_LIST_CAP claimed slots (fast finalize of small tables)
+    u32* fin_rank = nullptr;        // rank[KMC_OCC_LIST_CAP] + ticket counter of kmc_small_finalize_kernel (zero between launches)
     u64 *spill_hi = nullptr, *spill_lo = nullptr, *spill_cnt = nullptr;
     u64 spill_cap = 0;
 
@@ -810,6 +811,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->occ_list) (void)hipFree(c->occ_list);
+    if (c->fin_rank) (void)hipFree(c->fin_rank);
     if (c->spill_hi) (void)hipFree(c->spill_hi);
     if (c->spill_lo) (void)hipFree(c->spill_lo);
     if (c->spill_cnt) (void)hipFree(c->spill_cnt);
@@ -858,6 +860,8 @@ extern "C" int kmc_create(kmc_ctx** out, const kmc_config* cfg) {
         u64 cap = next_pow2(std::max<u64>(cfg->capacity_hint * 2, 1ull << 20));
         c->spill_cap = std::max<u64>(cap / 4, 1ull << 18);
         HIPCHK(c, hipMalloc((void**)&c->occ_list, KMC_OCC_LIST_CAP * sizeof(u64)));
+        HIPCHK(c, hipMalloc((void**)&c->fin_rank, (KMC_OCC_LIST_CAP + 16) * sizeof(u32)));
+        HIPCHK(c, hipMemsetAsync(c->fin_rank, 0, (KMC_OCC_LIST_CAP + 16) * sizeof(u32), c->stream));
         HIPCHK(c, hipMalloc((void**)&c->spill_lo, c->spill_cap * sizeof(u64)));
         HIPCHK(c, hipMalloc((void**)&c->spill_cnt, c->spill_cap * sizeof(u64)));
         if (c->KW == 2) HIPCHK(c, hipMalloc((void**)&c->spill_hi, c->spill_cap * sizeof(u64)));
@@ -998,8 +1002,9 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
         rc = ensure(c, c->o_cnt, fb); if (rc) return rc;
         if (c->KW == 2) { rc = ensure(c, c->o_hi, fb); if (rc) return rc; }
         GTable g = gtable_of(c, c->tab);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(1), dim3(1024), 0, c->stream, g, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
-        else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(1), dim3(1024), 0, c->stream, g, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+        const int fgrid = KMC_OCC_LIST_CAP / KMC_FIN_CHUNK;  // workgroups beyond ceil(n / 64) leave at once
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(fgrid), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+        else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(fgrid), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
         HIPCHK(c, hipGetLastError());
         tried_fast = true;
     }

@@ -170,145 +170,113 @@ __global__ void kmc_sum_kernel(const u64* cnt, u64 n, u64* counters) {
     if ((threadIdx.x & 63) == 0 && a) atomicAdd((unsigned long long*)&counters[KMC_CTR_SUM2], a);
 }
 
-// Fast finalize for small tables (n <= KMC_OCC_LIST_CAP claimed slots, listed in g.occ_list): ONE
-// workgroup gathers the keys, sorts them (bitonic network, ascending by (hi, lo)) and writes the
-// sorted view and the sum of counts -- instead of scanning the whole table, three library sort
-// launches and a gather.  This is the GPU form of the reference's final ordering step
-// (k-mer-count/src/main.rs:87) for the common case of a few thousand distinct keys.
+// Fast finalize for small tables (n <= KMC_OCC_LIST_CAP claimed slots, listed in g.occ_list): the GPU
+// form of the reference's final ordering step (k-mer-count/src/main.rs:87) for the common case of a
+// few thousand distinct keys, in ONE launch that uses the whole chip instead of one CU:
+//   rank sort -- keys in a table are distinct, so the sorted position of key i is the number of
+//   keys smaller than it.  Workgroup b holds 64 of the keys in LDS and adds, for EVERY key i, how
+//   many of its 64 are smaller (LDS broadcast reads, no data movement) to rank[i] with an
+//   agent-scope atomic; n*n/64 comparisons per workgroup, n/64 workgroups side by side.  The
+//   workgroup whose "done" ticket is the last one scatters (key, count) to position rank[i], sums
+//   the counts and leaves rank[] and the ticket counter zeroed for the next launch.
 // It is launched speculatively right behind the count kernels: it reads the occupancy on the device
 // and gives up (FASTFIN = 0) unless the table is small and nothing spilled, so kmc_finalize needs a
 // single host synchronisation.
-//
-// The network runs in REGISTERS: N = 1024 * E elements (E = 1, 2, 4, 8), thread t holds the elements
-// with sorted positions t*E .. t*E+E-1.  A compare-exchange at distance j is a register swap inside
-// the thread (j < E), a wave shuffle with lane ^ (j/E) (j < 64 E), and only for the widest distances
-// (j >= 64 E: 10 of the 78 passes at N = 4096) an exchange through LDS with a workgroup barrier.
-// (The first version kept the elements in LDS with a barrier after every pass: 56-60 us for 3,350
-// keys; making 68 of its passes wave-local did not help -- it was bound by LDS instruction issue on
-// one CU, not by the barriers.)
+// (History: a single-workgroup bitonic network took 55-60 us for 3,350 keys whether it ran in LDS
+// with workgroup barriers, in LDS with wave-local passes, or in registers with wave shuffles --
+// stamps: 6 us gather, 39 us network, 9 us output; one CU's LDS pipe carries all the data movement.)
+#define KMC_FIN_CHUNK 64
+#define KMC_FIN_PER_THREAD (KMC_OCC_LIST_CAP / 1024)
 template <int KW>
-__device__ __forceinline__ bool sf_gt(u64 ahi, u64 alo, u64 bhi, u64 blo) {
-    return KW == 2 ? (ahi > bhi || (ahi == bhi && alo > blo)) : alo > blo;
-}
-
-template <int KW, int E, int J>
-__device__ __forceinline__ void sf_in_thread(u64 (&lo)[E], u64 (&hi)[E], u32 (&ix)[E], u32 tbase, u32 kk) {
-#pragma unroll
-    for (int e = 0; e < E; ++e) {
-        if ((e & J) == 0 && (e | J) < E) {
-            const int p = e | J;
-            const bool up = ((tbase + e) & kk) == 0;
-            const bool gt = sf_gt<KW>(hi[e], lo[e], hi[p], lo[p]);
-            if (gt == up) {
-                u64 t = lo[e]; lo[e] = lo[p]; lo[p] = t;
-                if (KW == 2) { t = hi[e]; hi[e] = hi[p]; hi[p] = t; }
-                u32 x = ix[e]; ix[e] = ix[p]; ix[p] = x;
-            }
-        }
+__global__ __launch_bounds__(1024)
+void kmc_small_finalize_kernel(GTable g, u32* __restrict__ rank, u64* __restrict__ out_hi, u64* __restrict__ out_lo, u64* __restrict__ out_cnt) {
+    __shared__ u64 c_lo[KMC_FIN_CHUNK];
+    __shared__ u64 c_hi[KW == 2 ? KMC_FIN_CHUNK : 1];
+    __shared__ u32 s_last;
+    __shared__ u64 s_sum[16];
+    const u32 tid = threadIdx.x;
+    const u64 n = g.counters[KMC_CTR_OCCUPIED];
+    const bool ok = n > 0 && n <= KMC_OCC_LIST_CAP && n <= g.occ_list_cap && g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0;
+    if (!ok) {  // (every workgroup reads the same counters; nothing else writes them while this kernel runs)
+        if (blockIdx.x == 0 && tid == 0) { g.counters[KMC_CTR_FASTFIN] = 0; g.counters[KMC_CTR_SUM2] = 0; }
+        return;
     }
-}
-
-template <int KW, int E>
-__device__ __forceinline__ void small_finalize_sort(const GTable& g, u64 n, u64* __restrict__ out_hi, u64* __restrict__ out_lo,
-                                                    u64* __restrict__ out_cnt, u64* s_lo, u64* s_hi, unsigned short* s_ix) {
-    const u32 tid = threadIdx.x, lane = tid & 63;
-    constexpr u32 N = 1024u * E;
-    u64 lo[E], hi[E];
-    u32 ix[E];
-    // initial placement is arbitrary (we are sorting): slot e of thread t takes list entry e*1024 + t (coalesced)
+    const u32 nb = (u32)((n + KMC_FIN_CHUNK - 1) / KMC_FIN_CHUNK);
+    if (blockIdx.x >= nb) return;
+    // this workgroup's 64 keys (padding = all ones: never smaller than a valid key)
+    if (tid < KMC_FIN_CHUNK) {
+        const u64 j = (u64)blockIdx.x * KMC_FIN_CHUNK + tid;
+        u64 lo = ~0ull, hi = ~0ull;
+        if (j < n) {
+            const u64 slot = g.occ_list[j];
+            lo = g.key_lo[slot];
+            hi = KW == 2 ? g.key_hi[slot] : 0ull;
+        }
+        c_lo[tid] = lo;
+        if (KW == 2) c_hi[tid] = hi;
+    }
+    // every key of the table: up to 8 per thread, loaded together
+    u64 klo[KMC_FIN_PER_THREAD], khi[KMC_FIN_PER_THREAD];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const u32 i = (u32)e * 1024u + tid;
-        ix[e] = i;
+    for (int e = 0; e < KMC_FIN_PER_THREAD; ++e) {
+        const u64 i = (u64)e * 1024 + tid;
+        klo[e] = 0; khi[e] = 0;
         if (i < n) {
             const u64 slot = g.occ_list[i];
-            lo[e] = g.key_lo[slot];
-            hi[e] = KW == 2 ? g.key_hi[slot] : 0ull;
-        } else {  // padding sorts last (valid keys never have the top bits set)
-            lo[e] = ~0ull;
-            hi[e] = KW == 2 ? ~0ull : 0ull;
+            klo[e] = g.key_lo[slot];
+            if (KW == 2) khi[e] = g.key_hi[slot];
         }
     }
-    const u32 tbase = tid * E;
-    for (u32 kk = 2; kk <= N; kk <<= 1) {
-        for (u32 j = kk >> 1; j > 0; j >>= 1) {
-            if (j >= 64u * E) {
-                // partner lives in another wave: through LDS, element (t, e) at e*1024 + t (conflict-free)
-                const u32 pt = tid ^ (j / E);
-                __syncthreads();  // (the previous LDS pass's reads are done)
+    __syncthreads();
+    u32 r[KMC_FIN_PER_THREAD];
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    s_lo[e * 1024 + tid] = lo[e];
-                    if (KW == 2) s_hi[e * 1024 + tid] = hi[e];
-                    s_ix[e * 1024 + tid] = (unsigned short)ix[e];
-                }
-                __syncthreads();
-                const bool lower = (tid & (j / E)) == 0;
+    for (int e = 0; e < KMC_FIN_PER_THREAD; ++e) r[e] = 0;
+    for (int j = 0; j < KMC_FIN_CHUNK; ++j) {
+        const u64 cl = c_lo[j];
+        const u64 ch = KW == 2 ? c_hi[j] : 0ull;
 #pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const u64 plo = s_lo[e * 1024 + pt];
-                    const u64 phi = KW == 2 ? s_hi[e * 1024 + pt] : 0ull;
-                    const u32 pix = s_ix[e * 1024 + pt];
-                    const bool up = ((tbase + e) & kk) == 0;
-                    const bool want_min = lower == up;
-                    const bool take = want_min ? sf_gt<KW>(hi[e], lo[e], phi, plo) : sf_gt<KW>(phi, plo, hi[e], lo[e]);
-                    if (take) { lo[e] = plo; hi[e] = phi; ix[e] = pix; }
-                }
-            } else if (j >= (u32)E) {
-                const int m = (int)(j / E);  // lane xor mask, < 64
-                const bool lower = (lane & (u32)m) == 0;
-#pragma unroll
-                for (int e = 0; e < E; ++e) {
-                    const u64 plo = __shfl_xor(lo[e], m);
-                    const u64 phi = KW == 2 ? __shfl_xor(hi[e], m) : 0ull;
-                    const u32 pix = __shfl_xor(ix[e], m);
-                    const bool up = ((tbase + e) & kk) == 0;
-                    const bool want_min = lower == up;
-                    const bool take = want_min ? sf_gt<KW>(hi[e], lo[e], phi, plo) : sf_gt<KW>(phi, plo, hi[e], lo[e]);
-                    if (take) { lo[e] = plo; hi[e] = phi; ix[e] = pix; }
-                }
-            } else if (j == 4) {
-                sf_in_thread<KW, E, (E > 4 ? 4 : 1)>(lo, hi, ix, tbase, kk);
-            } else if (j == 2) {
-                sf_in_thread<KW, E, (E > 2 ? 2 : 1)>(lo, hi, ix, tbase, kk);
-            } else {
-                sf_in_thread<KW, E, 1>(lo, hi, ix, tbase, kk);
-            }
-        }
+        for (int e = 0; e < KMC_FIN_PER_THREAD; ++e)
+            r[e] += (KW == 2 ? (ch < khi[e] || (ch == khi[e] && cl < klo[e])) : cl < klo[e]) ? 1u : 0u;
     }
+#pragma unroll
+    for (int e = 0; e < KMC_FIN_PER_THREAD; ++e) {
+        const u64 i = (u64)e * 1024 + tid;
+        if (i < n && r[e]) atomicAdd(&rank[i], r[e]);
+    }
+    // every add of this workgroup has been performed before its ticket is drawn
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        const u32 t = atomicAdd(&rank[KMC_OCC_LIST_CAP], 1u);
+        s_last = (t == nb - 1) ? 1u : 0u;
+        if (s_last) __threadfence();
+    }
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last workgroup: scatter to sorted order ----
     u64 sum = 0;
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-        const u32 i = tbase + e;  // sorted position
+    for (int e = 0; e < KMC_FIN_PER_THREAD; ++e) {
+        const u64 i = (u64)e * 1024 + tid;
         if (i < n) {
-            const u64 c = g.count[g.occ_list[ix[e]]];
-            out_lo[i] = lo[e];
-            if (KW == 2) out_hi[i] = hi[e];
-            out_cnt[i] = c;
+            const u32 pos = __hip_atomic_load(&rank[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rank[i] = 0;
+            const u64 c = g.count[g.occ_list[i]];
+            out_lo[pos] = klo[e];
+            if (KW == 2) out_hi[pos] = khi[e];
+            out_cnt[pos] = c;
             sum += c;
         }
     }
     sum = wave_sum_u64(sum);
-    if (lane == 0 && sum) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_SUM2], sum);
-}
-
-template <int KW>
-__global__ __launch_bounds__(1024)
-void kmc_small_finalize_kernel(GTable g, u64* __restrict__ out_hi, u64* __restrict__ out_lo, u64* __restrict__ out_cnt) {
-    // exchange buffers of the widest passes (only E >= 2 has any: j >= 64 E needs N >= 128 E)
-    __shared__ u64 s_lo[KMC_OCC_LIST_CAP];
-    __shared__ u64 s_hi[KW == 2 ? KMC_OCC_LIST_CAP : 1];
-    __shared__ unsigned short s_ix[KMC_OCC_LIST_CAP];
-    const int tid = threadIdx.x;
-    const u64 n = g.counters[KMC_CTR_OCCUPIED];
-    const bool ok = n > 0 && n <= KMC_OCC_LIST_CAP && g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0;
-    __syncthreads();  // (every thread has read the counters before thread 0 rewrites two of them)
-    if (tid == 0) { g.counters[KMC_CTR_FASTFIN] = ok ? 1 : 0; g.counters[KMC_CTR_SUM2] = 0; }
-    if (!ok) return;
-    __threadfence();
+    if ((tid & 63) == 0) s_sum[tid >> 6] = sum;
     __syncthreads();
-    if (n <= 1024) small_finalize_sort<KW, 1>(g, n, out_hi, out_lo, out_cnt, s_lo, s_hi, s_ix);
-    else if (n <= 2048) small_finalize_sort<KW, 2>(g, n, out_hi, out_lo, out_cnt, s_lo, s_hi, s_ix);
-    else if (n <= 4096) small_finalize_sort<KW, 4>(g, n, out_hi, out_lo, out_cnt, s_lo, s_hi, s_ix);
-    else small_finalize_sort<KW, 8>(g, n, out_hi, out_lo, out_cnt, s_lo, s_hi, s_ix);
+    if (tid == 0) {
+        u64 tot = 0;
+        for (int w = 0; w < 16; ++w) tot += s_sum[w];
+        g.counters[KMC_CTR_SUM2] = tot;
+        g.counters[KMC_CTR_FASTFIN] = 1;
+        rank[KMC_OCC_LIST_CAP] = 0;
+    }
 }

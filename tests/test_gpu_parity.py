@@ -293,6 +293,55 @@ def test_device_resident_batches_and_synth(kmc, oracle):
                 assert np.array_equal(t2.count, want.count * 2) and np.array_equal(t2.key_lo, want.key_lo)
 
 
+def test_small_table_finalize_sizes(kmc):
+    """The rank-sort finalize of small tables at its size boundaries (64 keys per workgroup, 1024
+    threads, at most 8192 keys; 8193 takes the library sort), one- and two-word keys, repeated on the
+    same ctx (the kernel must leave its rank/ticket workspace clean)."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(55)
+    for k in (31, 63):
+        with kmc.KmerCounter(k=k) as kc:
+            for n in (1, 2, 63, 64, 65, 127, 1023, 1024, 1025, 3350, 4096, 8191, 8192, 8193, 20000, 64):
+                lo = rng.integers(0, 2**62, n, dtype=np.uint64)
+                hi = rng.integers(0, 2**60, n, dtype=np.uint64) if k > 31 else np.zeros(n, np.uint64)
+                if k > 31:
+                    hi[: n // 2] = hi[0]  # equal high words: the order is decided by the low word
+                cnt = rng.integers(1, 1000, n, dtype=np.uint64)
+                key = (hi.astype(object) << 64) | lo.astype(object)
+                assert len(set(key.tolist())) == n
+                d_lo = torch.from_numpy(lo.astype(np.int64)).cuda()
+                d_hi = torch.from_numpy(hi.astype(np.int64)).cuda()
+                d_c = torch.from_numpy(cnt.astype(np.int64)).cuda()
+                torch.cuda.synchronize()
+                kc.reset()
+                kc.merge_pairs_device(d_hi.data_ptr() if k > 31 else 0, d_lo.data_ptr(), d_c.data_ptr(), n)
+                t = kc.export()
+                order = np.lexsort((lo, hi))
+                assert t.n_distinct == n and t.n_total == int(cnt.sum())
+                assert np.array_equal(t.key_hi, hi[order]) and np.array_equal(t.key_lo, lo[order]) and np.array_equal(t.count, cnt[order]), (k, n)
+
+
+def test_poll_and_forget_source(kmc, oracle):
+    """kmc_poll brings the stats up to date without a finalize (the multi-GPU step packs the live
+    table and never finalizes the counting ctx); kmc_forget_source drops the walk memo and the
+    planner history without touching counts."""
+    bases, offs = oracle.parse_fasta(SAMPLE)
+    want = oracle.count_kmers(bases, offs, 31, True)
+    with kmc.KmerCounter(k=31, algo=kmc.ALGO_WALK) as kc:
+        kc.add_batch(bases, offs)
+        kc.poll()
+        st = kc.stats()
+        assert st.n_kmers == want.n_total and st.kernel_ms_last > 0 and st.launches_last >= 1
+        kc.forget_source(memo=True, history=True)
+        kc.add_batch(bases, offs)          # counts survive; the second batch re-learns the memo
+        t = kc.export()
+        assert np.array_equal(t.key_lo, want.key_lo) and np.array_equal(t.count, want.count * 2)
+        kc.reset()
+        kc.forget_source(memo=True, history=False)
+        kc.add_batch(bases, offs)
+        assert kc.export().equals(want)
+
+
 def test_merge_and_partition(kmc, oracle):
     """Multi-GPU reduce building blocks on one GPU: owner partition + merge == counting everything."""
     rng = np.random.default_rng(21)
