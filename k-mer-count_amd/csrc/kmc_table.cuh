@@ -216,15 +216,18 @@ void kmc_small_finalize_kernel(GTable g, u32* __restrict__ rank, u64* __restrict
         if (KW == 2) c_hi[tid] = hi;
     }
     // every key of the table: up to 8 per thread, loaded together
-    u64 klo[KMC_FIN_PER_THREAD], khi[KMC_FIN_PER_THREAD];
+    // (and its count: only the last workgroup needs them, but loading them here takes two memory
+    // round trips off the end of the kernel's dependency chain)
+    u64 klo[KMC_FIN_PER_THREAD], khi[KMC_FIN_PER_THREAD], kcnt[KMC_FIN_PER_THREAD];
 #pragma unroll
     for (int e = 0; e < KMC_FIN_PER_THREAD; ++e) {
         const u64 i = (u64)e * 1024 + tid;
-        klo[e] = 0; khi[e] = 0;
+        klo[e] = 0; khi[e] = 0; kcnt[e] = 0;
         if (i < n) {
             const u64 slot = g.occ_list[i];
             klo[e] = g.key_lo[slot];
             if (KW == 2) khi[e] = g.key_hi[slot];
+            kcnt[e] = g.count[slot];
         }
     }
     __syncthreads();
@@ -262,7 +265,7 @@ void kmc_small_finalize_kernel(GTable g, u32* __restrict__ rank, u64* __restrict
         if (i < n) {
             const u32 pos = __hip_atomic_load(&rank[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             rank[i] = 0;
-            const u64 c = g.count[g.occ_list[i]];
+            const u64 c = kcnt[e];
             out_lo[pos] = klo[e];
             if (KW == 2) out_hi[pos] = khi[e];
             out_cnt[pos] = c;
