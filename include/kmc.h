@@ -181,6 +181,13 @@ int kmc_get_stats(const kmc_ctx* ctx, kmc_stats* out);
  * uses, main.rs:45-46,59-62), feed batches, finalize.  Results via kmc_export. */
 int kmc_count_file(kmc_ctx* ctx, const char* path, uint64_t* n_distinct, uint64_t* n_total);
 
+/* The same on several GPUs of this process (the CLI's --gpus N): ctxs[0..n_ctx) are distinct
+ * contexts with the same k / mode / canonical, normally one per GPU; chunks of the file go
+ * round-robin to them and the tables are reduced into ctxs[0] (peer copies + kmc_merge_pairs_device),
+ * which holds the result (kmc_export).  Scaling runs use one process per GPU and RCCL instead
+ * (k-mer-count_amd/distributed.py). */
+int kmc_count_file_multi(kmc_ctx** ctxs, uint32_t n_ctx, const char* path, uint64_t* n_distinct, uint64_t* n_total);
+
 /* Host FASTA reader on its own (library-owned buffers; free with kmc_free_reads). */
 typedef struct kmc_reads {
     uint8_t*  bases;

@@ -81,6 +81,7 @@ ABI_SYMBOLS = [
     "kmc_synth_reads_host", "kmc_synth_reads_device", "kmc_synth_write_fasta",
     "kmc_slab_words", "kmc_pack_slab_device", "kmc_merge_slabs_device", "kmc_forget_source",
     "kmc_fasta_stream_open", "kmc_fasta_stream_next", "kmc_fasta_stream_close", "kmc_poll",
+    "kmc_count_file_multi",
 ]
 
 _lib = None
@@ -142,6 +143,7 @@ def lib() -> C.CDLL:
     L.kmc_forget_source.argtypes = [vp, i32]
     L.kmc_poll.argtypes = [vp]
     L.kmc_count_file.argtypes = [vp, C.c_char_p, pu64, pu64]
+    L.kmc_count_file_multi.argtypes = [C.POINTER(vp), u32, C.c_char_p, pu64, pu64]
     L.kmc_parse_fasta.argtypes = [C.c_char_p, C.POINTER(_Reads), C.c_char_p, C.c_size_t]
     L.kmc_free_reads.argtypes = [C.POINTER(_Reads)]
     L.kmc_free_reads.restype = None
@@ -400,6 +402,18 @@ class KmerCounter:
         s = Stats()
         self._chk(self._L.kmc_get_stats(self._h, C.byref(s)))
         return s
+
+
+def count_file_multi(counters, path: str) -> Tuple[int, int]:
+    """One FASTA file on several ctxs of this process (normally one per GPU); counters[0] holds the
+    reduced table afterwards."""
+    L = lib()
+    arr = (C.c_void_p * len(counters))(*[c._h for c in counters])
+    nd, nt = C.c_uint64(), C.c_uint64()
+    rc = L.kmc_count_file_multi(arr, len(counters), os.fsencode(path), C.byref(nd), C.byref(nt))
+    if rc:
+        raise KmcError(rc, L.kmc_last_error(counters[0]._h).decode())
+    return nd.value, nt.value
 
 
 def owner_of(key_hi: int, key_lo: int, n_parts: int) -> int:

@@ -1308,25 +1308,20 @@ static int count_file_whole(kmc_ctx* c, const char* path, uint64_t* n_distinct, 
     return kmc_finalize(c, n_distinct, n_total);
 }
 
-// FASTA path in, table out (the reference's File::open + Reader + record loop, main.rs:44-46,58-62,
-// feeding the window loop).  Pipeline: the streaming reader (kmc_ingest.h) parses chunk j+1 on the
-// host cores into one of two pinned buffers while the GPU uploads and counts chunk j; the reader's
-// per-thread pieces go straight to their dense place in the device buffer, so the host never
-// stitches or copies the sequence a second time.
-extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
-    if (!c || !path) return KMC_ERR_ARG;
-    HIPCHK(c, hipSetDevice(c->cfg.device));
+static int count_file_pipeline(kmc_ctx** ctxs, uint32_t n_ctx, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
+    kmc_ctx* c0 = ctxs[0];
     u64 chunk_bytes = 256ull << 20;
     if (const char* e = getenv("KMC_INGEST_CHUNK_BYTES")) { u64 v = strtoull(e, nullptr, 10); if (v) chunk_bytes = v; }
     KmcFastaIngest ing;
     std::string err;
     int rc = ing.open(path, chunk_bytes, &err);
-    if (rc == KMC_ERR_IO && err != "Error during opening the file") return count_file_whole(c, path, n_distinct, n_total);  // (not mappable)
-    if (rc) return fail(c, rc, "%s: %s", path, err.c_str());
+    if (rc == KMC_ERR_IO && err != "Error during opening the file" && n_ctx == 1) return count_file_whole(c0, path, n_distinct, n_total);  // (not mappable)
+    if (rc) return fail(c0, rc, "%s: %s", path, err.c_str());
     const u64 cap = ing.chunk_capacity();
-    struct Pinned { uint8_t* bases = nullptr; u64* offs = nullptr; u64 offs_cap = 0; hipEvent_t ev = nullptr; bool busy = false; } pin[2];
+    struct Pinned { uint8_t* bases = nullptr; u64* offs = nullptr; u64 offs_cap = 0; hipEvent_t ev = nullptr; bool busy = false; };
+    std::vector<Pinned> pin((size_t)n_ctx * 2);  // two per ctx
     auto cleanup = [&]() {
-        (void)hipStreamSynchronize(c->stream);
+        for (uint32_t i = 0; i < n_ctx; ++i) { (void)hipSetDevice(ctxs[i]->cfg.device); (void)hipStreamSynchronize(ctxs[i]->stream); }
         for (auto& p : pin) {
             if (p.bases) (void)hipHostFree(p.bases);
             if (p.offs) (void)hipHostFree(p.offs);
@@ -1335,18 +1330,20 @@ extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct
     };
     auto body = [&]() -> int {
         KmcIngestChunk ck;
-        const bool lr = c->cfg.mode == KMC_MODE_LR;
-        for (int j = 0;; ++j) {
-            Pinned& p = pin[j & 1];
+        const bool lr = c0->cfg.mode == KMC_MODE_LR;
+        for (u64 j = 0;; ++j) {
+            kmc_ctx* c = ctxs[j % n_ctx];  // chunks go round-robin over the GPUs
+            Pinned& p = pin[(size_t)(j % n_ctx) * 2 + ((j / n_ctx) & 1)];
+            HIPCHK(c, hipSetDevice(c->cfg.device));
             if (!p.bases) {
                 HIPCHK(c, hipHostMalloc((void**)&p.bases, (size_t)cap));
                 HIPCHK(c, hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
             }
-            if (p.busy) { HIPCHK(c, hipEventSynchronize(p.ev)); p.busy = false; }  // its upload two chunks ago has finished
+            if (p.busy) { HIPCHK(c, hipEventSynchronize(p.ev)); p.busy = false; }  // its upload two rounds ago has finished
             int r;
-            try { r = ing.next(p.bases, lr, &ck, &err); } catch (const std::bad_alloc&) { return fail(c, KMC_ERR_NOMEM, "out of memory while parsing %s", path); }
-            if (r) return fail(c, r, "%s: %s", path, err.c_str());
-            if (lr && ck.bad_byte >= 0) return fail(c, KMC_ERR_ALPHABET, "Unexpected charactor %c appears", ck.bad_byte);  // main.rs:23
+            try { r = ing.next(p.bases, lr, &ck, &err); } catch (const std::bad_alloc&) { return fail(c0, KMC_ERR_NOMEM, "out of memory while parsing %s", path); }
+            if (r) return fail(c0, r, "%s: %s", path, err.c_str());
+            if (lr && ck.bad_byte >= 0) return fail(c0, KMC_ERR_ALPHABET, "Unexpected charactor %c appears", ck.bad_byte);  // main.rs:23
             if (ck.n_reads) {
                 if (p.offs_cap < ck.n_reads + 1) {
                     if (p.offs) { HIPCHK(c, hipHostFree(p.offs)); p.offs = nullptr; }
@@ -1354,20 +1351,21 @@ extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct
                     HIPCHK(c, hipHostMalloc((void**)&p.offs, (size_t)p.offs_cap * sizeof(u64)));
                 }
                 memcpy(p.offs, ck.offsets.data(), (size_t)(ck.n_reads + 1) * sizeof(u64));
-                // settle the previous batch first (it may still read the staging buffers; its kernels finished
-                // long ago -- this chunk took longer to parse), then queue upload + count without waiting
-                if (c->pending) { r = poll_and_settle(c); if (r) return r; }
+                // settle the ctx's previous batch first (it may still read the staging buffers; its kernels
+                // finished long ago -- this chunk took longer to parse), then queue upload + count without waiting
+                auto fwd = [&](int code) { if (c != c0) c0->err = c->err; return code; };
+                if (c->pending) { r = poll_and_settle(c); if (r) return fwd(r); }
                 r = ensure(c, c->st_bases, ck.n_bases + 64);
-                if (r) return r;
+                if (r) return fwd(r);
                 r = ensure(c, c->st_offsets, (ck.n_reads + 1) * sizeof(u64));
-                if (r) return r;
+                if (r) return fwd(r);
                 for (const auto& pc : ck.pieces)
                     HIPCHK(c, hipMemcpyAsync((uint8_t*)c->st_bases.p + pc.dst_off, p.bases + pc.src_off, (size_t)pc.n_bytes, hipMemcpyHostToDevice, c->stream));
                 HIPCHK(c, hipMemcpyAsync(c->st_offsets.p, p.offs, (size_t)(ck.n_reads + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
                 HIPCHK(c, hipEventRecord(p.ev, c->stream));
                 p.busy = true;
                 r = count_batch_device(c, (const uint8_t*)c->st_bases.p, (const u64*)c->st_offsets.p, ck.n_reads, ck.n_bases, ck.max_read_len);
-                if (r) return r;
+                if (r) return fwd(r);
             }
             if (ck.eof) break;
         }
@@ -1376,7 +1374,53 @@ extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct
     rc = body();
     cleanup();
     if (rc) return rc;
-    return kmc_finalize(c, n_distinct, n_total);
+    // reduce: every other GPU's sorted table is copied to ctxs[0]'s GPU (peer copy: xGMI) and merged there
+    for (uint32_t i = 1; i < n_ctx; ++i) {
+        kmc_ctx* c = ctxs[i];
+        u64 nd = 0, nt = 0;
+        rc = kmc_finalize(c, &nd, &nt);
+        if (rc) { c0->err = c->err; return rc; }
+        if (!nd) continue;
+        HIPCHK(c0, hipSetDevice(c0->cfg.device));
+        const int words = c0->KW + 1;
+        u64* tmp = nullptr;
+        HIPCHK(c0, hipMalloc((void**)&tmp, (size_t)nd * words * sizeof(u64)));
+        hipError_t e = hipMemcpyPeerAsync(tmp, c0->cfg.device, c->v_lo, c->cfg.device, (size_t)nd * sizeof(u64), c0->stream);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(tmp + nd, c0->cfg.device, c->v_cnt, c->cfg.device, (size_t)nd * sizeof(u64), c0->stream);
+        if (e == hipSuccess && c0->KW == 2) e = hipMemcpyPeerAsync(tmp + 2 * nd, c0->cfg.device, c->v_hi, c->cfg.device, (size_t)nd * sizeof(u64), c0->stream);
+        if (e == hipSuccess) {
+            rc = kmc_merge_pairs_device(c0, c0->KW == 2 ? tmp + 2 * nd : nullptr, tmp, tmp + nd, nd);
+            if (!rc) e = hipStreamSynchronize(c0->stream);
+        }
+        (void)hipFree(tmp);
+        if (e != hipSuccess) return fail(c0, KMC_ERR_HIP, "peer copy from device %d failed: %s", c->cfg.device, hipGetErrorString(e));
+        if (rc) return rc;
+    }
+    return kmc_finalize(c0, n_distinct, n_total);
+}
+
+// FASTA path in, table out (the reference's File::open + Reader + record loop, main.rs:44-46,58-62,
+// feeding the window loop).  Pipeline: the streaming reader (kmc_ingest.h) parses chunk j+1 on the
+// host cores into one of two pinned buffers while the GPU uploads and counts chunk j; the reader's
+// per-thread pieces go straight to their dense place in the device buffer, so the host never
+// stitches or copies the sequence a second time.
+extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
+    if (!c || !path) return KMC_ERR_ARG;
+    return count_file_pipeline(&c, 1, path, n_distinct, n_total);
+}
+
+// The same on several GPUs of ONE process (the CLI's --gpus N): chunks go round-robin to the ctxs,
+// each with its own pinned double buffer, and the tables are reduced into ctxs[0] by peer copies.
+// (Scaling runs use one process per GPU and RCCL instead: k-mer-count_amd/distributed.py.)
+extern "C" int kmc_count_file_multi(kmc_ctx** ctxs, uint32_t n_ctx, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
+    if (!ctxs || !n_ctx || !path) return KMC_ERR_ARG;
+    for (uint32_t i = 0; i < n_ctx; ++i) {
+        if (!ctxs[i]) return KMC_ERR_ARG;
+        if (ctxs[i]->cfg.k != ctxs[0]->cfg.k || ctxs[i]->cfg.mode != ctxs[0]->cfg.mode || ctxs[i]->cfg.canonical != ctxs[0]->cfg.canonical)
+            return fail(ctxs[0], KMC_ERR_ARG, "kmc_count_file_multi: ctx %u differs from ctx 0 in k, mode or canonical", i);
+        for (uint32_t j = 0; j < i; ++j) if (ctxs[j] == ctxs[i]) return fail(ctxs[0], KMC_ERR_ARG, "kmc_count_file_multi: ctx %u listed twice", i);
+    }
+    return count_file_pipeline(ctxs, n_ctx, path, n_distinct, n_total);
 }
 
 extern "C" int kmc_synth_reads_device(const kmc_synth* s, uint64_t first_record, uint64_t n_records, void* d_bases,

@@ -4,7 +4,10 @@
 // cwd (main.rs:44) and prints one sorted 54-character line per occurrence (main.rs:88-90);
 // test.py:15-18 takes the FASTA path as its only positional argument.  This tool keeps both:
 //
-//   k-mer-count [FASTA] [-k K] [--forward] [--expand] [--device N] [--algo auto|stream|walk|sort] [--stats]
+//   k-mer-count [FASTA] [-k K] [--forward] [--expand] [--device N | --gpus N] [--algo auto|stream|walk|sort] [--stats]
+//
+//   --gpus N  the file's chunks go round-robin to GPUs 0..N-1 of this process, tables reduced on GPU 0
+//             (there is no CPU backend: SURVEY.md's "--backend cpu" is deliberately absent)
 //
 //   no -k   reference mode: LR-gapped 27+gap+27 for sizes 80..=140, expanded sorted output,
 //           byte-identical to main.rs:87-90
@@ -27,7 +30,7 @@ static int die(const char* what, const char* msg) {
 
 int main(int argc, char** argv) {
     const char* path = "sample.fasta";  // main.rs:44
-    int k = 0, canonical = 1, expand = 0, device = 0, algo = KMC_ALGO_AUTO, stats = 0;
+    int k = 0, canonical = 1, expand = 0, device = 0, algo = KMC_ALGO_AUTO, stats = 0, gpus = 1;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a == "-k" && i + 1 < argc) k = atoi(argv[++i]);
@@ -35,11 +38,12 @@ int main(int argc, char** argv) {
         else if (a == "--expand") expand = 1;
         else if (a == "--stats") stats = 1;
         else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
+        else if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
         else if (a == "--algo" && i + 1 < argc) {
             std::string v = argv[++i];
             algo = v == "stream" ? KMC_ALGO_STREAM : v == "walk" ? KMC_ALGO_WALK : v == "sort" ? KMC_ALGO_SORT : KMC_ALGO_AUTO;
         } else if (a == "-h" || a == "--help") {
-            fprintf(stderr, "usage: k-mer-count [FASTA] [-k K] [--forward] [--expand] [--device N] [--algo auto|stream|walk|sort] [--stats]\n");
+            fprintf(stderr, "usage: k-mer-count [FASTA] [-k K] [--forward] [--expand] [--device N | --gpus N] [--algo auto|stream|walk|sort] [--stats]\n");
             return 0;
         } else if (!a.empty() && a[0] != '-') path = argv[i];
         else { fprintf(stderr, "k-mer-count: unknown option %s\n", a.c_str()); return 2; }
@@ -53,15 +57,26 @@ int main(int argc, char** argv) {
     cfg.device = device;
     cfg.algo = algo;
     if (!k) expand = 1;
-    kmc_ctx* ctx = nullptr;
-    int rc = kmc_create(&ctx, &cfg);
-    if (rc) return die("kmc_create", kmc_last_error(nullptr));
+    if (gpus < 1 || gpus > 64) { fprintf(stderr, "k-mer-count: --gpus must be 1..64\n"); return 2; }
+    // KMC_CLI_SHARE_DEVICE=D (testing on a box with fewer GPUs): all --gpus contexts live on device D
+    const char* share = getenv("KMC_CLI_SHARE_DEVICE");
+    std::vector<kmc_ctx*> ctxs;
+    int rc = 0;
+    for (int g = 0; g < gpus && !rc; ++g) {
+        cfg.device = gpus == 1 ? device : (share ? atoi(share) : g);
+        kmc_ctx* one = nullptr;
+        rc = kmc_create(&one, &cfg);
+        if (!rc) ctxs.push_back(one);
+    }
+    auto destroy_all = [&]() { for (kmc_ctx* x : ctxs) kmc_destroy(x); };
+    if (rc) { int r = die("kmc_create", kmc_last_error(nullptr)); destroy_all(); return r; }
+    kmc_ctx* ctx = ctxs[0];
     uint64_t nd = 0, nt = 0;
-    rc = kmc_count_file(ctx, path, &nd, &nt);
-    if (rc) { int r = die(path, kmc_last_error(ctx)); kmc_destroy(ctx); return r; }
+    rc = gpus == 1 ? kmc_count_file(ctx, path, &nd, &nt) : kmc_count_file_multi(ctxs.data(), (uint32_t)ctxs.size(), path, &nd, &nt);
+    if (rc) { int r = die(path, kmc_last_error(ctx)); destroy_all(); return r; }
     std::vector<uint64_t> hi(nd ? nd : 1), lo(nd ? nd : 1), cnt(nd ? nd : 1);
     rc = kmc_export(ctx, hi.data(), lo.data(), cnt.data(), nd);
-    if (rc) { int r = die("kmc_export", kmc_last_error(ctx)); kmc_destroy(ctx); return r; }
+    if (rc) { int r = die("kmc_export", kmc_last_error(ctx)); destroy_all(); return r; }
     const int klen = k ? k : 54;
     std::vector<char> obuf(1 << 22);
     setvbuf(stdout, obuf.data(), _IOFBF, obuf.size());
@@ -85,6 +100,6 @@ int main(int argc, char** argv) {
                 (unsigned long long)s.n_distinct, (unsigned long long)s.table_capacity, (unsigned long long)s.n_spilled,
                 s.kernel_ms_last, s.algo_last);
     }
-    kmc_destroy(ctx);
+    destroy_all();
     return 0;
 }

@@ -781,3 +781,36 @@ def test_config4_50GB_eight_shards_reduced_on_one_gpu(kmc, oracle):
     hb, ho = kmc.synth_reads_host(s, 0, 200_000)
     sample = oracle.count_kmers(hb, ho, k, True, method=1)
     assert np.array_equal(whole.key_lo, sample.key_lo) and np.all(whole.count >= sample.count)
+
+
+def test_count_file_on_several_contexts_and_cli_gpus(kmc, oracle, tmp_path, monkeypatch):
+    """kmc_count_file_multi / `k-mer-count --gpus N`: the file's chunks go round-robin to N contexts
+    (one per GPU; on this one-GPU box they share the device), the tables are reduced into the first
+    by peer copies + merge.  Same table as one context, in count-table mode and in the reference's
+    LR mode (golden digest of the reference's own output)."""
+    import hashlib
+    import subprocess
+    from conftest import ROOT
+    monkeypatch.setenv("KMC_INGEST_CHUNK_BYTES", "9000")
+    bases, offs = oracle.parse_fasta(SAMPLE)
+    for k in (31, 63):
+        want = oracle.count_kmers(bases, offs, k, True)
+        cs = [kmc.KmerCounter(k=k) for _ in range(3)]
+        try:
+            nd, nt = kmc.count_file_multi(cs, SAMPLE)
+            assert (nd, nt) == (want.n_distinct, want.n_total)
+            assert cs[0].export().equals(want)
+            assert all(c.stats().n_batches >= 3 for c in cs)   # 10 chunks over 3 contexts
+        finally:
+            for c in cs:
+                c.close()
+    exe = os.path.join(ROOT, "bin", "k-mer-count")
+    env = dict(os.environ, KMC_CLI_SHARE_DEVICE="0", KMC_INGEST_CHUNK_BYTES="9000")
+    out = subprocess.run([exe, SAMPLE, "-k", "21", "--gpus", "4"], capture_output=True, check=True, env=env).stdout
+    ref = subprocess.run([oracle.ORACLE_CLI, "count", SAMPLE, "21"], capture_output=True, check=True).stdout
+    assert out == ref
+    out = subprocess.run([exe, SAMPLE, "--gpus", "2"], capture_output=True, check=True, env=env).stdout
+    assert hashlib.sha256(out).hexdigest() == LR["G-full"]["sha256"]
+    # more GPUs than the box has: a clean error, exit code 101, nothing on stdout
+    r = subprocess.run([exe, SAMPLE, "-k", "21", "--gpus", "64"], capture_output=True, env=dict(os.environ))
+    assert r.returncode == 101 and r.stdout == b"" and b"kmc_create" in r.stderr
