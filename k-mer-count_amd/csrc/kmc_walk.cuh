@@ -75,6 +75,7 @@ struct WalkLds {
     WalkEdge edge[KMC_WALK_ECAP];
     u32 badbits[KMC_WALK_WAVES][KMC_WALK_BADWORDS];
     u32 nedges, nnodes;
+    u32 qnext;  // next unclaimed tile of this workgroup (waves draw their tiles from it)
 };
 
 // workspace (device): [WalkWs header | gcnt[NCAP+ECAP] dense snapshot counters | u32 deferred read
@@ -373,7 +374,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         L.node[i].prim = warm ? memo->prim[i] : 0ull;
         L.node[i].cnt = 0;
     }
-    if (tid == 0) { L.nedges = warm ? memo->nedges : 0; L.nnodes = warm ? memo->nnodes : 1; }
+    if (tid == 0) { L.nedges = warm ? memo->nedges : 0; L.nnodes = warm ? memo->nnodes : 1; L.qnext = KMC_WALK_WAVES; }
     __syncthreads();
     const WCtx root_key = node_encode<KW>(WCtx{0, 0}, 0, k, mask_hi, mask_lo);  // prefix node of depth 0
     u32 root_id = (u32)(kmc_hash_key<KW>(root_key.hi, root_key.lo) >> (64 - KMC_WALK_NLOG));
@@ -385,28 +386,51 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     u32* stage = L.stage[wv];
     u64 nk = 0, ndirect = 0;
     const u64 n_tiles = tile_end;  // this launch covers tiles [tile_begin, tile_end) of 64 reads
-    // wave ids interleave the workgroups (wave wv of every workgroup before wave wv+1 of any), so the
-    // last, partial round of tiles is spread over all CUs instead of filling the first third of them
-    const u64 gw = tile_begin + (u64)wv * gridDim.x + blockIdx.x;
-    const u64 total_waves = (u64)gridDim.x * KMC_WALK_WAVES;
+    // Workgroup b owns the tiles tile_begin + b + gridDim.x * j, j = 0, 1, ... (interleaved over the
+    // workgroups, so every CU gets the same share whatever the batch size), and its waves DRAW them
+    // from a counter in LDS instead of owning a fixed sixteenth each: the SIMD arbiter favours a
+    // workgroup's older waves, which ran 86 tiles in the time the younger ones needed for 68 --
+    // with fixed shares they went idle at 70 % of the kernel's run time and the CU finished on half
+    // its waves, i.e. half its bytes in flight (in-kernel stamps: tile loops done at 1058 .. 1519 us).
+    // (Workgroups still finish 25 us apart.  Leaving the last 4 / 8 / 16 % of the tiles to pools shared
+    // by 8 workgroups, drawn with a global atomic, made the kernel 2 / 2.5 / 5 % SLOWER: the returning
+    // atomic at tile entry drains the wave's loads in flight.)
+    auto tile_of = [&](u32 j) { return tile_begin + blockIdx.x + (u64)gridDim.x * j; };
+    const u64 gw = tile_of((u32)wv);  // the first tile of every wave is fixed; the counter starts behind them
 
     // Per-tile geometry: the wave's 64 reads are the byte range [A, B) of the batch.
+    // Geometry comes in two steps so that a tile's successor costs no stall: tile_load only ISSUES the
+    // two offset loads (at the entry of the tile before), tile_finish turns them into the byte range
+    // when that tile's last round is about to be issued, four rounds of loads later -- by then they
+    // have long arrived.  (Done in one step at tile entry, the wave-wide shuffles forced
+    // s_waitcnt vmcnt(0) there, twice: every tile began by draining the wave's loads in flight and
+    // then sat through a second memory round trip with nothing in flight at all.)
+    struct TileRaw { u64 a, e; u32 have; };
     struct TileGeo { u64 a, e, A, B, A16; u32 n_pieces; u32 have; };
-    auto tile_geo = [&](u64 tile) {
-        TileGeo t;
+    auto tile_load = [&](u64 tile) {
+        TileRaw w;
         const u64 r = tile * 64 + lane;
-        t.have = r < n_reads ? 1u : 0u;
+        w.have = r < n_reads ? 1u : 0u;
         // read r is bases [vstart[r], vend[r]).  Short-read batches pass offsets and offsets + 1; batches
         // with reads longer than KMC_WALK_MAX_READ pass the pieces made by kmc_vreads_* (consecutive
         // pieces of a read overlap by k-1 bases; starts and ends are non-decreasing either way)
-        t.e = vend[t.have ? r : n_reads - 1];
-        t.a = t.have ? vstart[r] : t.e;
+        const u64 idx = w.have ? r : n_reads - 1;
+        w.e = vend[idx];
+        w.a = vstart[idx];
+        return w;
+    };
+    auto tile_finish = [&](const TileRaw& w) {
+        TileGeo t;
+        t.have = w.have;
+        t.e = w.e;
+        t.a = w.have ? w.a : w.e;  // lanes past the last read hold the last end twice
         t.A = __shfl(t.a, 0);
-        t.B = __shfl(t.e, 63);  // lanes past the last read hold the last end twice
+        t.B = __shfl(t.e, 63);
         t.A16 = t.A & ~15ull;
         t.n_pieces = (u32)((t.B - t.A16 + 15) >> 4);
         return t;
     };
+    auto tile_geo = [&](u64 tile) { return tile_finish(tile_load(tile)); };
     // One round = KMC_WALK_LPR coalesced 1 KiB wave-loads: pieces base + 64*u + lane of the byte range
     // that starts at A16.  Branch-free on purpose (straight-line code lets the compiler keep counted
     // s_waitcnt vmcnt(N) and two rounds in flight): a piece index past the end is clamped to the
@@ -548,24 +572,42 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     u64 tile = gw;
     bool live = gw < n_tiles;  // wave-uniform
     bool has_next = false;
+    u64 nxt_tile = 0;
+    TileRaw nxt_raw = {0, 0, 0};
     u32 rbase = 0;
     if (live) { cur = tile_geo(tile); nxt = cur; issue(va, cur.A16, cur.n_pieces ? cur.n_pieces - 1 : 0, 0); }
     auto half = [&](uint4 (&x)[LPR], uint4 (&y)[LPR]) {
         const u32 np_u = (u32)__builtin_amdgcn_readfirstlane((int)cur.n_pieces);
+        // The successor's offsets (tile_load, at the entry of this tile) are "used" here, at the top of
+        // every half-iteration: in the one after the tile entry that costs a counted wait for loads that
+        // are older than the round about to be consumed anyway; in all others nothing.  Without it the
+        // compiler has to put an s_waitcnt vmcnt(0) in front of tile_finish, which would drain the
+        // round in flight at every tile's last round.
+        asm volatile("" ::"v"(nxt_raw.a), "v"(nxt_raw.e));
+        const bool last = rbase + RP >= np_u;  // wave-uniform: this is the tile's last round
         if (rbase == 0) {  // tile entry
             if (lane < KMC_WALK_BADWORDS) L.badbits[wv][lane] = 0;
             anybad = false;
-            has_next = tile + total_waves < n_tiles;
-            if (has_next) nxt = tile_geo(tile + total_waves);
+            u32 jn = 0;
+            if (lane == 0) jn = atomicAdd(&L.qnext, 1u);
+            nxt_tile = tile_of((u32)__builtin_amdgcn_readfirstlane((int)jn));
+            has_next = nxt_tile < n_tiles;
+            if (has_next) nxt_raw = tile_load(nxt_tile);
+            // a one-round tile needs its successor's geometry right behind the loads and has to wait for them
+            if (last && has_next) { asm volatile("; tile_finish right behind tile_load"); nxt = tile_finish(nxt_raw); }
+        } else if (last && has_next) {
+            // every other tile: rounds later, and no path from tile_load leads here except through the
+            // use above (a second copy on purpose: merged with the one-round case, its s_waitcnt
+            // vmcnt(0) would serve both)
+            nxt = tile_finish(nxt_raw);
         }
-        const bool last = rbase + RP >= np_u;  // wave-uniform: this is the tile's last round
         const u32 cur_last = cur.n_pieces ? cur.n_pieces - 1 : 0, nxt_last = nxt.n_pieces ? nxt.n_pieces - 1 : 0;
         issue(y, last ? nxt.A16 : cur.A16, last ? nxt_last : cur_last, last ? 0u : rbase + RP);
         consume(x, cur, rbase, np_u);
         if (last) {
             step_phase(cur, tile);
             cur = nxt;
-            tile += total_waves;
+            tile = nxt_tile;
             rbase = 0;
             live = has_next;
         } else {
