@@ -204,7 +204,9 @@ void kmc_free_reads(kmc_reads* r);
  * point into the stream's own buffers and stay valid until the next call on the stream (do NOT
  * pass them to kmc_free_reads).  *eof is set to 1 with the last chunk.  This is what a host
  * program (the Rust main() of INTEGRATION.md) feeds to kmc_add_batch chunk by chunk;
- * kmc_count_file uses the same reader internally and overlaps parsing with upload and counting. */
+ * kmc_count_file uses the same reader internally and overlaps parsing with upload and counting.
+ * Extension (not in the reference): a file whose first byte is '@' is read as
+ * four-line FASTQ and only its sequence lines are handed on. */
 typedef struct kmc_fasta_stream kmc_fasta_stream;
 int  kmc_fasta_stream_open(const char* path, uint64_t chunk_bytes, kmc_fasta_stream** out, char* errbuf, size_t errbuf_len);
 int  kmc_fasta_stream_next(kmc_fasta_stream* s, kmc_reads* out, int* eof, char* errbuf, size_t errbuf_len);

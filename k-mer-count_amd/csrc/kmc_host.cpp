@@ -230,7 +230,64 @@ void parse_piece(const char* text, uint64_t b, uint64_t e, bool file_start, bool
     po->n_bytes = (uint64_t)(o - out);
 }
 
+// four-line FASTQ records of text[b, e) (b is a record start)
+void parse_piece_fastq(const char* text, uint64_t b, uint64_t e, bool check_alphabet, uint8_t* out, PieceOut* po) {
+    const char* p = text + b;
+    const char* const end = text + e;
+    uint8_t* o = out;
+    unsigned phase = 0;
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* le = nl ? nl : end;
+        if (phase == 0) {
+            if (le == p && !nl) break;            // (nothing after the last newline)
+            if (*p != '@') { po->bad_first_line = true; break; }
+            po->rec_start.push_back((uint64_t)(o - out));
+            po->rec_blank.push_back(0);
+        } else if (phase == 1) {
+            const char* t = le;
+            while (t > p && is_space((unsigned char)t[-1])) t--;
+            const size_t n = (size_t)(t - p);
+            memcpy(o, p, n);
+            if (check_alphabet && po->bad_byte < 0) {
+                for (size_t i = 0; i < n; ++i) {
+                    const uint8_t c = (uint8_t)p[i];
+                    if (c != 'A' && c != 'C' && c != 'G' && c != 'T') { po->bad_byte = c; break; }
+                }
+            }
+            o += n;
+        } else if (phase == 2) {
+            if (le == p || *p != '+') { po->bad_first_line = true; break; }
+        }
+        phase = (phase + 1) & 3;
+        if (!nl) break;
+        p = nl + 1;
+    }
+    po->n_bytes = (uint64_t)(o - out);
+}
+
 }  // namespace
+
+// first FASTQ record start at or after q (< limit), else limit: a line that starts with '@' whose
+// second successor starts with '+' (a quality line may start with '@' too, but then the line two
+// further down is a sequence, which never starts with '+')
+uint64_t KmcFastaIngest::fastq_record_start(uint64_t q, uint64_t limit) const {
+    if (q == 0) return 0;
+    const char* nl = (const char*)memchr(map_ + q - 1, '\n', (size_t)(limit - q + 1));
+    if (!nl) return limit;
+    uint64_t ls = (uint64_t)(nl - map_) + 1;
+    for (int tries = 0; tries < 8 && ls < limit; ++tries) {
+        const char* n1 = (const char*)memchr(map_ + ls, '\n', (size_t)(size_ - ls));
+        if (!n1) return limit;
+        const uint64_t l1 = (uint64_t)(n1 - map_) + 1;
+        const char* n2 = l1 < size_ ? (const char*)memchr(map_ + l1, '\n', (size_t)(size_ - l1)) : nullptr;
+        if (!n2) return limit;
+        const uint64_t l2 = (uint64_t)(n2 - map_) + 1;
+        if (map_[ls] == '@' && l2 < size_ && map_[l2] == '+') return ls;
+        ls = l1;
+    }
+    return limit;
+}
 
 KmcFastaIngest::~KmcFastaIngest() {
     if (map_ && size_) munmap((void*)map_, (size_t)size_);
@@ -252,12 +309,14 @@ int KmcFastaIngest::open(const char* path, uint64_t chunk_bytes, std::string* er
     chunk_bytes_ = std::max<uint64_t>(chunk_bytes, 1);
     unsigned hw = std::thread::hardware_concurrency();
     threads_ = std::max(1u, std::min(hw ? hw : 1u, 32u));
+    fastq_ = size_ > 0 && map_[0] == '@';
     // chunk boundaries: the first record start ("\n>") at or after every multiple of chunk_bytes
     cuts_.assign(1, 0);
     uint64_t at = 0;
     while (size_ - at > chunk_bytes_) {
         uint64_t q = at + chunk_bytes_;
         uint64_t cut = size_;
+        if (fastq_) { cut = fastq_record_start(q, size_); q = size_; }
         while (q < size_) {
             const char* nl = (const char*)memchr(map_ + q, '\n', (size_t)(size_ - q));
             if (!nl) break;
@@ -296,6 +355,7 @@ int KmcFastaIngest::next(uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* 
     for (uint64_t i = 1; i < nseg; ++i) {
         uint64_t q = cb + len * i / nseg;
         if (q < sb[(size_t)i - 1]) q = sb[(size_t)i - 1];
+        if (fastq_) { sb[(size_t)i] = std::max(sb[(size_t)i - 1], fastq_record_start(q, ce)); continue; }  // FASTQ pieces start at records
         const char* nl = q < ce ? (const char*)memchr(map_ + q - 1, '\n', (size_t)(ce - q + 1)) : nullptr;  // line start: byte after a '\n' at >= q-1
         sb[(size_t)i] = nl ? (uint64_t)(nl - map_) + 1 : ce;
     }
@@ -305,13 +365,19 @@ int KmcFastaIngest::next(uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* 
         std::vector<std::thread> th;
         for (uint64_t i = 1; i < nseg; ++i) {
             po[(size_t)i].src_off = sb[(size_t)i] - cb;
-            th.emplace_back(parse_piece, map_, sb[(size_t)i], sb[(size_t)i + 1], false, check_alphabet, out_buf + po[(size_t)i].src_off, &po[(size_t)i]);
+            if (fastq_) th.emplace_back(parse_piece_fastq, map_, sb[(size_t)i], sb[(size_t)i + 1], check_alphabet, out_buf + po[(size_t)i].src_off, &po[(size_t)i]);
+            else th.emplace_back(parse_piece, map_, sb[(size_t)i], sb[(size_t)i + 1], false, check_alphabet, out_buf + po[(size_t)i].src_off, &po[(size_t)i]);
         }
-        parse_piece(map_, sb[0], sb[1], cb == 0, check_alphabet, out_buf, &po[0]);
+        if (fastq_) parse_piece_fastq(map_, sb[0], sb[1], check_alphabet, out_buf, &po[0]);
+        else parse_piece(map_, sb[0], sb[1], cb == 0, check_alphabet, out_buf, &po[0]);
         for (auto& t : th) t.join();
     } catch (const std::system_error&) {
         if (err) *err = "cannot start parser threads";
         return KMC_ERR_NOMEM;
+    }
+    if (fastq_) {
+        for (auto& p : po)
+            if (p.bad_first_line) { if (err) *err = "malformed FASTQ record (expected '@' header and '+' separator lines)"; done_ = true; return KMC_ERR_FORMAT; }
     }
     if (po[0].bad_first_line) { if (err) *err = "Expected > at record start."; done_ = true; return KMC_ERR_FORMAT; }
     uint64_t base = 0;
@@ -327,7 +393,7 @@ int KmcFastaIngest::next(uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* 
     ck->offsets.push_back(base);
     ck->eof = next_cut_ + 1 >= cuts_.size();
     // Record::is_empty(): a record with empty header and no sequence ends the input (main.rs:60-62)
-    for (uint64_t i = 0; i < nrec; ++i) {
+    for (uint64_t i = 0; i < nrec && !fastq_; ++i) {
         if (blank[(size_t)i] && ck->offsets[(size_t)i + 1] == ck->offsets[(size_t)i]) {
             nrec = i;
             base = ck->offsets[(size_t)i];

@@ -8,7 +8,9 @@
 // coordination and nothing is stitched on the host.  kmc_count_file uploads the workers' pieces
 // straight to their final (dense) place in the device buffer and parses the next chunk while the
 // GPU copies and counts this one.  Semantics are those of kmc_parse_fasta (the reader the
-// reference uses, k-mer-count/src/main.rs:45-46,59-62).
+// reference uses, k-mer-count/src/main.rs:45-46,59-62).  Extension the reference does not have
+// (parity unpinned): a file whose first byte is '@' is read as four-line FASTQ --
+// header, sequence, '+' line, quality -- of which only the sequence line reaches the GPU.
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
@@ -47,5 +49,7 @@ class KmcFastaIngest {
     std::vector<uint64_t> cuts_;  // chunk boundaries (record starts), cuts_[0] = 0 ... cuts_.back() = size_
     size_t next_cut_ = 0;
     bool done_ = false;
+    bool fastq_ = false;  // the file starts with '@': four-line FASTQ records (header, sequence, '+', quality)
     unsigned threads_ = 1;
+    uint64_t fastq_record_start(uint64_t q, uint64_t limit) const;
 };

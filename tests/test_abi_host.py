@@ -224,3 +224,49 @@ def test_streaming_reader_multi_thread_chunks(kmc, oracle, tmp_path):
     for cb in (0, 10_000_000):
         b1, o1, _ = _stream_all(kmc, str(q), cb)
         assert o1.tolist() == [0, 35_000_000, 50_000_000] and np.array_equal(o1, o2) and np.array_equal(b1, b2)
+
+
+def _fastq_text(rng, n_rec, eol=b"\n", final_eol=True, max_len=300):
+    """Random four-line FASTQ with N's and with quality strings that start with '@' or '+'."""
+    recs, seqs = [], []
+    for i in range(n_rec):
+        L = int(rng.integers(0, max_len + 1))
+        seq = np.frombuffer(b"ACGTN", np.uint8)[rng.choice(5, L, p=[0.24, 0.24, 0.24, 0.24, 0.04])].tobytes()
+        qual = np.frombuffer(b"@+!IIIIFFF#5", np.uint8)[rng.integers(0, 12, L)].tobytes()
+        if L and i % 3 == 0:
+            qual = b"@" + qual[1:]
+        if L and i % 5 == 0:
+            qual = b"+" + qual[1:]
+        recs.append(b"@read%d some text" % i + eol + seq + eol + b"+" + (b"read%d" % i if i % 2 else b"") + eol + qual + eol)
+        seqs.append(seq)
+    text = b"".join(recs)
+    if not final_eol and text.endswith(eol):
+        text = text[:-len(eol)]
+    offs = np.zeros(n_rec + 1, np.uint64)
+    offs[1:] = np.cumsum([len(s) for s in seqs])
+    return text, np.frombuffer(b"".join(seqs), np.uint8), offs
+
+
+def test_streaming_reader_fastq(kmc, tmp_path):
+    """Extension the reference does not have (parity unpinned): a file that starts
+    with '@' is read as four-line FASTQ; only the sequence lines are handed on.  Every chunking, CRLF,
+    missing final newline, quality lines that look like headers, multi-threaded chunks."""
+    rng = np.random.default_rng(8)
+    for eol, final_eol, n_rec in ((b"\n", True, 300), (b"\r\n", True, 120), (b"\n", False, 77), (b"\n", True, 1)):
+        text, bases, offs = _fastq_text(rng, n_rec, eol, final_eol)
+        p = tmp_path / "r.fastq"
+        p.write_bytes(text)
+        for cb in (1, 50, 997, 20000, 0):
+            b1, o1, _ = _stream_all(kmc, str(p), cb)
+            assert np.array_equal(o1, offs) and np.array_equal(b1, bases), (eol, final_eol, n_rec, cb)
+    text, bases, offs = _fastq_text(rng, 120_000, max_len=250)   # ~32 MB: several worker pieces per chunk
+    p = tmp_path / "big.fastq"
+    p.write_bytes(text)
+    for cb in (0, 9_000_000):
+        b1, o1, n = _stream_all(kmc, str(p), cb)
+        assert np.array_equal(o1, offs) and np.array_equal(b1, bases), cb
+    bad = tmp_path / "bad.fastq"
+    bad.write_bytes(b"@r1\nACGT\nIIII\n@r2\nAC\n+\nII\n")       # '+' line missing in the first record
+    with pytest.raises(kmc.KmcError) as e:
+        list(kmc.stream_fasta(str(bad)))
+    assert e.value.status == kmc.ERR_FORMAT

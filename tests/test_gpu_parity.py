@@ -814,3 +814,21 @@ def test_count_file_on_several_contexts_and_cli_gpus(kmc, oracle, tmp_path, monk
     # more GPUs than the box has: a clean error, exit code 101, nothing on stdout
     r = subprocess.run([exe, SAMPLE, "-k", "21", "--gpus", "64"], capture_output=True, env=dict(os.environ))
     assert r.returncode == 101 and r.stdout == b"" and b"kmc_create" in r.stderr
+
+
+def test_count_file_fastq(kmc, oracle, tmp_path, monkeypatch):
+    """FASTQ in, table out (reader extension, parity unpinned by the reference): the table equals the
+    oracle's count over the sequence lines; reads carry N's (windows skipped) and are ragged."""
+    import test_abi_host as th
+    rng = np.random.default_rng(18)
+    text, bases, offs = th._fastq_text(rng, 5000, max_len=400)
+    p = tmp_path / "reads.fastq"
+    p.write_bytes(text)
+    for cb in ("", "100000"):
+        if cb:
+            monkeypatch.setenv("KMC_INGEST_CHUNK_BYTES", cb)
+        for k in (21, 63):
+            want = oracle.count_kmers(bases, offs, k, True)
+            with kmc.KmerCounter(k=k) as kc:
+                nd, nt = kc.count_file(str(p))
+                assert (nd, nt) == (want.n_distinct, want.n_total) and kc.export().equals(want), (cb, k)

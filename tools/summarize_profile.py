@@ -20,6 +20,12 @@ durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.Dic
 full = [d for d in durs if d >= 0.8 * max(durs)]
 full = full[-5:]  # the timed steps (the warm-up steps before them run at a lower clock)
 avg_ns = sum(full) / len(full); calls = len(full)
+# the same --stats columns over the timed steps' launches only (the raw file's average also contains the
+# few small launches of the first, history-less step)
+with open(dst + "_kernel_stats_timed_steps.csv", "w") as f:
+    f.write('"Name","Calls","TotalDurationNs","AverageNs","MinNs","MaxNs","Note"\n')
+    f.write('"%s",%d,%d,%.1f,%d,%d,"last %d full-batch launches of %s (from the kernel trace of the same run)"\n'
+            % (kname, calls, int(sum(full)), avg_ns, int(min(full)), int(max(full)), calls, os.path.basename(stats)))
 ctr = collections.defaultdict(list)
 for f in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.csv"))):
     rows = [r for r in csv.DictReader(open(f)) if kname in r["Kernel_Name"]]
