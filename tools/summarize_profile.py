@@ -16,9 +16,12 @@ shutil.copy(stats, dst + "_kernel_stats.csv")
 # full-batch launches (duration >= 80 % of the longest) are averaged below.  The raw --stats file
 # (all launches) is kept next to this summary.
 trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
-durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in csv.DictReader(open(trace)) if kname in r["Kernel_Name"]]
-full = [d for d in durs if d >= 0.8 * max(durs)]
-full = full[-5:]  # the timed steps (the warm-up steps before them run at a lower clock)
+rows_t = sorted((r for r in csv.DictReader(open(trace)) if kname in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+durs = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in rows_t]
+import statistics
+thr = 0.75 * statistics.median(durs[-5:])  # the run ends with full-batch launches; the first step's ramp launches are shorter
+full = [d for d in durs if d >= thr]  # full-batch launches, in time order
+full = full[-5:]  # the 5 timed steps of tools/profile_bench.sh (the warm-up steps before them run at a lower clock)
 avg_ns = sum(full) / len(full); calls = len(full)
 # the same --stats columns over the timed steps' launches only (the raw file's average also contains the
 # few small launches of the first, history-less step)
@@ -31,9 +34,12 @@ for f in sorted(glob.glob(os.path.join(src, "pmc*", "*", "*_counter_collection.c
     rows = [r for r in csv.DictReader(open(f)) if kname in r["Kernel_Name"]]
     if not rows:
         continue
-    dmax = max(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in rows)
-    for r in rows:
-        if float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) >= 0.8 * dmax:
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    dd = [float(r["End_Timestamp"]) - float(r["Start_Timestamp"]) for r in rows]
+    n_ctr = len({r["Counter_Name"] for r in rows})
+    thr_p = 0.75 * statistics.median(dd[-5 * n_ctr:])
+    for r, d in zip(rows, dd):
+        if d >= thr_p:
             ctr[r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {c: sum(v) / len(v) for c, v in ctr.items()}
 # MI355X_MICROARCH.md "HBM": FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports exactly
