@@ -270,3 +270,23 @@ def test_streaming_reader_fastq(kmc, tmp_path):
     with pytest.raises(kmc.KmcError) as e:
         list(kmc.stream_fasta(str(bad)))
     assert e.value.status == kmc.ERR_FORMAT
+
+
+def test_host_code_under_sanitizers(kmc, tmp_path):
+    """kmc_host.cpp (readers, FASTQ, decode, generator) built with -fsanitize=address,undefined and
+    run over edge-case files with several chunk sizes; the harness also checks streamed == whole-file."""
+    exe = tmp_path / "host_reader_san"
+    src = [os.path.join(ROOT, "tests", "native", "host_reader_san.cpp"), os.path.join(ROOT, "k-mer-count_amd", "csrc", "kmc_host.cpp")]
+    r = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                        "-I", os.path.join(ROOT, "include"), "-o", str(exe)] + src, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    cases = {"a.fasta": b">r1 desc\nACGT  \r\nAC\n\n>r2\n>r3\nGG", "b.fasta": b"", "c.fasta": b">a\n", "d.fasta": b">a\nAC\n>\n>b\nGG\n",
+             "e.fasta": b"ACGT\n>r\nAC\n", "f.fasta": b">x\n" + b"ACGT" * 5000 + b"\n>y\n\n\n>z\nT", "g.fasta": b"\n", "h.fasta": b">",
+             "i.fastq": b"@r1\nACGT\n+\nIIII\n@r2\nAC\n+r2\n@I\n", "j.fastq": b"@r1\nACGT\nIIII\n", "k.fastq": b"@", "l.fastq": b"@r\nAC\n+\nII"}
+    files = []
+    for name, data in cases.items():
+        (tmp_path / name).write_bytes(data)
+        files.append(str(tmp_path / name))
+    files += [SAMPLE, str(tmp_path / "missing.fasta")]
+    r = subprocess.run([str(exe)] + files, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1500:], r.stderr[-3000:])
