@@ -21,12 +21,17 @@
 // to per-occurrence counting.  When a memo table is full the lane counts its k-mers directly
 // (global atomics) -- always exact, just slower; KMC_ALGO_AUTO then prefers the stream kernel.
 //
-// Data movement.  A wave owns 64 consecutive reads = one contiguous byte range of the batch.
-// It streams that range with fully coalesced 16-byte loads, packs every 16 ASCII bases into one
-// 2-bit word in registers and parks the words in its private LDS staging area (4x smaller than
-// the ASCII); each lane then reads its own read back 16 bases at a time, re-aligned with
-// v_alignbit.  HBM traffic is the algorithmic minimum: every base byte and offset once.
-// Reads that contain a non-ACGT byte are diverted to a scalar kernel (kmc_scalar_reads_kernel).
+// Data movement.  A tile is 64 consecutive reads = one contiguous byte range of the batch.  A wave
+// streams its tile with fully coalesced 16-byte loads (two rounds of 5 KiB in flight, one stream of
+// rounds across tiles), packs every 16 ASCII bases into one 2-bit word in registers and parks the
+// words in its private LDS staging area (4x smaller than the ASCII); each lane then reads its own
+// read back 16 bases at a time, re-aligned with v_alignbit.  HBM traffic is the algorithmic
+// minimum: every base byte and offset once.  The waves of a workgroup DRAW their tiles from a
+// counter in LDS (the SIMD arbiter favours older waves; with fixed shares half of them idled for
+// the last third of the kernel).  Reads longer than KMC_WALK_MAX_READ are walked as pieces that
+// overlap by k-1 bases (kmc_vreads_*).  Reads that contain a non-ACGT byte are diverted to a scalar
+// kernel (kmc_scalar_reads_kernel).  Measured: 1.33 ms for 8.95 G bases = 6.8 TB/s, 85 % of the HBM
+// peak.
 #pragma once
 #include "../../include/kmc.h"
 #include "kmc_device.cuh"
