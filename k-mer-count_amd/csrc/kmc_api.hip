@@ -1310,8 +1310,17 @@ static int count_file_whole(kmc_ctx* c, const char* path, uint64_t* n_distinct, 
 
 static int count_file_pipeline(kmc_ctx** ctxs, uint32_t n_ctx, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
     kmc_ctx* c0 = ctxs[0];
-    u64 chunk_bytes = 256ull << 20;
+    // chunk size: a sixteenth of the file between 32 and 128 MiB (measured on 1 and 4 GB files, 16 host
+    // threads: 64-128 MiB is best -- 0.072 s / 0.24 s; 256 MiB chunks cost 0.10 / 0.26 s: the two pinned
+    // buffers take longer to allocate and the first upload starts later); KMC_INGEST_CHUNK_BYTES overrides
+    u64 chunk_bytes = 0;
     if (const char* e = getenv("KMC_INGEST_CHUNK_BYTES")) { u64 v = strtoull(e, nullptr, 10); if (v) chunk_bytes = v; }
+    if (!chunk_bytes) {
+        FILE* f = fopen(path, "rb");
+        u64 fsize = 0;
+        if (f) { if (fseeko(f, 0, SEEK_END) == 0) fsize = (u64)ftello(f); fclose(f); }
+        chunk_bytes = std::min<u64>(std::max<u64>(fsize / 16, 32ull << 20), 128ull << 20);
+    }
     KmcFastaIngest ing;
     std::string err;
     int rc = ing.open(path, chunk_bytes, &err);
