@@ -577,27 +577,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     HIPCHK(c, hipEventRecord(c->ev0, c->stream));
     c->lev_used = 0;
     int rc = KMC_OK;
-    if (c->cfg.mode == KMC_MODE_LR) {
-        // every window start contributes up to 61 new keys: make room first (exact worst case)
-        {
-            u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
-            u64 worst = occ + n_bases * (KMC_LR_SMAX - KMC_LR_SMIN + 1);
-            if (worst * 2 > c->tab.cap) {
-                u64 want = next_pow2(worst * 2);
-                if (want > (1ull << 33)) return fail(c, KMC_ERR_CAPACITY, "LR batch too large: %llu bases need %llu table slots; feed smaller batches",
-                                                     (unsigned long long)n_bases, (unsigned long long)want);
-                rc = grow_to(c, want);
-                if (rc) return rc;
-            }
-        }
-        rc = launch_begin(c);
-        if (rc) return rc;
-        rc = kmc_lr_launch(c->stream, c->n_cu, d_bases, d_offsets, n_reads, n_bases, gtable_of(c, c->tab));
-        if (rc) return fail(c, rc, "LR kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-        rc = launch_end(c);
-        if (rc) return rc;
-        c->pending = true;
-    } else {
+    {
         // Sub-batches.  A launch over n k-mers can add at most n new keys, so without history the
         // first launch is sized to what the table and spill area absorb for certain and later ones
         // ramp up (x16 at most) using the observed ratio rho = new keys per k-mer.  With history
@@ -640,8 +620,34 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             c->rho_hist = (double)(occ_all > c->b_occ0 ? occ_all - c->b_occ0 : 0) / std::max(observed_kmers, 1.0);
             return KMC_OK;
         };
+        const bool lr = c->cfg.mode == KMC_MODE_LR;
+        if (lr) {
+            // Reference mode: every window start contributes up to 61 keys (27 + gap + 27 for sizes
+            // 80..=140).  Ranges of window starts go through the same planner as the contiguous
+            // kernels (61 "k-mers" per position), so the table follows the number of DISTINCT keys
+            // (the first version grew it to the worst case 2 x 61 x bases before its single launch:
+            // 268 M slots for 1.6 M bases with 2 M distinct keys -- 20 of that run's 25 ms went into
+            // allocating, clearing and compacting an almost empty table).
+            const u64 per = KMC_LR_SMAX - KMC_LR_SMIN + 1;
+            c->b_kmers = std::max<u64>(n_bases * per, 1);
+            u64 done = 0, prev = 0;
+            while (done < n_bases) {
+                u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
+                u64 take = plan(n_bases - done, per, prev);
+                rc = launch_begin(c);
+                if (rc) return rc;
+                rc = kmc_lr_launch(c->stream, c->n_cu, d_bases, d_offsets, n_reads, n_bases, done, done + take, gtable_of(c, c->tab));
+                if (rc) return fail(c, rc, "LR kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+                rc = launch_end(c);
+                if (rc) return rc;
+                c->pending = true;
+                done += take;
+                prev = take;
+                if (done < n_bases) { rc = observe(occ, take, per); if (rc) return rc; }
+            }
+        }
         u64 stream_from = 0;  // base position from which the stream / sort path takes over
-        bool run_stream = (algo == KMC_ALGO_STREAM);
+        bool run_stream = (algo == KMC_ALGO_STREAM) && !lr;
         bool run_sort = (algo == KMC_ALGO_SORT);
         const bool is_auto = c->cfg.algo == KMC_ALGO_AUTO;
         if (algo == KMC_ALGO_WALK) {

