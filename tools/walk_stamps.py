@@ -1,4 +1,5 @@
-"""Diagnostic: per-wave phase stamps of kmc_walk_kernel from the libkmc_wstamps.so variant."""
+"""Diagnostic: per-wave phase stamps of kmc_walk_kernel.  Build the variant with tools/build_walk_stamps.py, then
+KMC_LIB_PATH=k-mer-count_amd/libkmc_wstamps.so python tools/walk_stamps.py"""
 import ctypes as C, importlib, os, sys
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
