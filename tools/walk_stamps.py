@@ -25,6 +25,9 @@ for it in range(8):
     desc("wave start", st[:, :, 0]); desc("LDS init done", st[:, :, 1]); desc("first tile loaded", st[:, :, 2]); desc("first tile stepped", st[:, :, 3])
     desc("tile loop done", st[:, :, 4]); desc("wave end (after flush)", st[:, :, 5])
     wg_done = st[:, :, 4].max(axis=1); desc("per-WG last wave loop done", wg_done)
+    wd = us(wg_done)
+    print("  per-WG loop done by blockIdx % 8 (XCD): " + " ".join(f"{wd[x::8].mean():7.1f}" for x in range(8)) + f"   (std within {np.mean([wd[x::8].std() for x in range(8)]):.1f} us)")
+    print("  per-WG loop done by blockIdx // 32:     " + " ".join(f"{wd[32 * x:32 * x + 32].mean():7.1f}" for x in range(8)))
     print("  tiles per wave:", np.unique(st[:, :, 6], return_counts=True))
     dur = us(st[:, :, 4]) - us(st[:, :, 1])
     for t in np.unique(st[:, :, 6])[[0, -1]]:
