@@ -398,12 +398,14 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     // with fixed shares they went idle at 70 % of the kernel's run time and the CU finished on half
     // its waves, i.e. half its bytes in flight (in-kernel stamps: tile loops done at 1058 .. 1519 us).
     // (Workgroups still finish up to 50 us apart -- by XCD: the 32 workgroups of an XCD end within 5 us of
-    // each other, the XCDs do not, and WHICH ones are slow changes from launch to launch.  Two attempts
+    // each other, the XCDs do not, and WHICH ones are slow changes from launch to launch.  Three attempts
     // to even that out did not pay: leaving the last 4 / 8 / 16 % of the tiles to pools shared by 8
-    // workgroups, drawn with a global atomic, made the kernel 2 / 2.5 / 5 % SLOWER (the returning
-    // atomic at tile entry drains the wave's loads in flight); per-XCD tile shares learned from the
-    // previous launch's loop times changed nothing (1.319 vs 1.320 ms), the past launch does not
-    // predict the next.)
+    // workgroups (one per XCD), drawn with a global atomic at tile entry, made the kernel 2 / 2.5 / 5 %
+    // SLOWER; drawing those tickets two tiles ahead so that nothing waits for the atomic made it 3 / 7 /
+    // 12 % slower still -- vector memory returns in issue order, so a returning device-scope atomic
+    // (microseconds under load) holds back every load the wave issued after it, however late its
+    // result is read; per-XCD tile shares learned from the previous launch's loop times changed
+    // nothing (1.319 vs 1.320 ms), the past launch does not predict the next.)
     auto tile_of = [&](u32 j) { return tile_begin + blockIdx.x + (u64)gridDim.x * j; };
     const u64 gw = tile_of((u32)wv);  // the first tile of every wave is fixed; the counter starts behind them
 
