@@ -171,6 +171,11 @@ int kmc_merge_slabs_device(kmc_ctx* ctx, const void* d_slabs, uint32_t n_slabs, 
  * reduce: the live table is packed and shipped, only the owner's table is finalized). */
 int kmc_poll(kmc_ctx* ctx);
 
+/* How KMC_ALGO_WALK cuts a read of read_len bases into pieces of at most 416 bases that overlap by
+ * k-1 (every window of the read lies in exactly one piece): the number of pieces, and, for the
+ * first `cap`, their [start, end) within the read.  Pure host arithmetic (no GPU needed). */
+uint64_t kmc_read_pieces(uint64_t read_len, int k, uint64_t* starts, uint64_t* ends, uint64_t cap);
+
 #define KMC_FORGET_MEMO 1     /* the walk kernel's memo snapshot */
 #define KMC_FORGET_HISTORY 2  /* the launch planner's history (and the AUTO algorithm choice) */
 int kmc_forget_source(kmc_ctx* ctx, int what);

@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "kmc_synth_reads_host", "kmc_synth_reads_device", "kmc_synth_write_fasta",
     "kmc_slab_words", "kmc_pack_slab_device", "kmc_merge_slabs_device", "kmc_forget_source",
     "kmc_fasta_stream_open", "kmc_fasta_stream_next", "kmc_fasta_stream_close", "kmc_poll",
-    "kmc_count_file_multi",
+    "kmc_count_file_multi", "kmc_read_pieces",
 ]
 
 _lib = None
@@ -142,6 +142,8 @@ def lib() -> C.CDLL:
     L.kmc_merge_slabs_device.argtypes = [vp, vp, u32, u64, u32, u32]
     L.kmc_forget_source.argtypes = [vp, i32]
     L.kmc_poll.argtypes = [vp]
+    L.kmc_read_pieces.argtypes = [u64, i32, vp, vp, u64]
+    L.kmc_read_pieces.restype = u64
     L.kmc_count_file.argtypes = [vp, C.c_char_p, pu64, pu64]
     L.kmc_count_file_multi.argtypes = [C.POINTER(vp), u32, C.c_char_p, pu64, pu64]
     L.kmc_parse_fasta.argtypes = [C.c_char_p, C.POINTER(_Reads), C.c_char_p, C.c_size_t]

@@ -1249,6 +1249,15 @@ extern "C" int kmc_merge_slabs_device(kmc_ctx* c, const void* d_slabs, uint32_t 
     return KMC_OK;
 }
 
+// How the walk kernel cuts a read of read_len bases into pieces (host copy of the device arithmetic,
+// kmc_vreads_of / kmc_vread_span): used by the CPU tests to check that every window lies in exactly one piece.
+extern "C" uint64_t kmc_read_pieces(uint64_t read_len, int k, uint64_t* starts, uint64_t* ends, uint64_t cap) {
+    if (k < 1 || k > KMC_WALK_MAX_K) return 0;
+    const u64 n = kmc_vreads_of(read_len, k);
+    for (u64 j = 0; j < n && j < cap && starts && ends; ++j) kmc_vread_span(0, read_len, k, j, &starts[j], &ends[j]);
+    return n;
+}
+
 extern "C" int kmc_poll(kmc_ctx* c) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));

@@ -791,6 +791,12 @@ __host__ __device__ inline u64 kmc_vreads_of(u64 len, int k) {
     const u64 S = KMC_WALK_MAX_READ - (u64)(k - 1);
     return (len - (u64)(k - 1) + S - 1) / S;
 }
+// piece j of a read that occupies bases [a, e): [*st, *en)
+__host__ __device__ inline void kmc_vread_span(u64 a, u64 e, int k, u64 j, u64* st, u64* en) {
+    const u64 S = KMC_WALK_MAX_READ - (u64)(k - 1);
+    *st = a + j * S;
+    *en = (e - *st > KMC_WALK_MAX_READ) ? *st + KMC_WALK_MAX_READ : e;
+}
 __global__ void kmc_vreads_count_kernel(const u64* __restrict__ offsets, u64 n_reads, int k, u64* __restrict__ cnt) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += (u64)gridDim.x * blockDim.x)
         cnt[i] = kmc_vreads_of(offsets[i + 1] - offsets[i], k);
@@ -798,17 +804,13 @@ __global__ void kmc_vreads_count_kernel(const u64* __restrict__ offsets, u64 n_r
 // pos = exclusive scan of cnt; piece v belongs to the read i with pos[i] <= v < pos[i+1] (every read has >= 1 piece)
 __global__ void kmc_vreads_fill_kernel(const u64* __restrict__ offsets, const u64* __restrict__ pos, u64 n_reads, u64 n_v, int k,
                                        u64* __restrict__ vstart, u64* __restrict__ vend) {
-    const u64 S = KMC_WALK_MAX_READ - (u64)(k - 1);
     for (u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x; v < n_v; v += (u64)gridDim.x * blockDim.x) {
         u64 lo = 0, hi = n_reads;  // last i with pos[i] <= v
         while (hi - lo > 1) {
             const u64 mid = (lo + hi) >> 1;
             if (pos[mid] <= v) lo = mid; else hi = mid;
         }
-        const u64 a = offsets[lo], e = offsets[lo + 1], j = v - pos[lo];
-        const u64 st = a + j * S;
-        vstart[v] = st;
-        vend[v] = (e - st > KMC_WALK_MAX_READ) ? st + KMC_WALK_MAX_READ : e;
+        kmc_vread_span(offsets[lo], offsets[lo + 1], k, v - pos[lo], &vstart[v], &vend[v]);
     }
 }
 // memo buffer: two snapshot slots + the dense counter array

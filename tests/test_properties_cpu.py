@@ -105,3 +105,27 @@ def test_synth_ranges_are_consistent(kmc, seed, first, n):
     b2, _ = kmc.synth_reads_host(s, first + n // 2, n - n // 2)
     assert np.array_equal(b[(n // 2) * 400:], b2)
     assert len(np.unique(b.reshape(-1, 80), axis=0)) <= 10
+
+
+@settings(max_examples=300, deadline=None)
+@given(st.integers(0, 5000), st.integers(1, 63))
+def test_walk_pieces_partition_the_windows(kmc, read_len, k):
+    """KMC_ALGO_WALK walks a read longer than 416 bases as pieces that overlap by k-1 bases
+    (kmc_read_pieces = the host copy of the device arithmetic).  Every window [i, i+k) of the read
+    must lie completely inside exactly one piece, pieces are at most 416 bases, in order, inside
+    the read; a short read is its own single piece."""
+    L = kmc.lib()
+    cap = 64
+    starts = np.zeros(cap, np.uint64)
+    ends = np.zeros(cap, np.uint64)
+    n = int(L.kmc_read_pieces(read_len, k, starts.ctypes.data, ends.ctypes.data, cap))
+    assert 1 <= n <= cap
+    sp, ep = starts[:n].astype(np.int64), ends[:n].astype(np.int64)
+    assert np.all(ep - sp <= 416) and np.all(sp >= 0) and np.all(ep <= read_len) and np.all(np.diff(sp) > 0 if n > 1 else True)
+    if read_len <= 416:
+        assert n == 1 and sp[0] == 0 and ep[0] == read_len
+    owners = np.zeros(max(read_len - k + 1, 0), np.int64)
+    for s_, e_ in zip(sp, ep):
+        if e_ - s_ >= k:
+            owners[s_:e_ - k + 1] += 1      # windows starting at s_ .. e_-k lie inside [s_, e_)
+    assert np.all(owners == 1)
