@@ -832,3 +832,22 @@ def test_count_file_fastq(kmc, oracle, tmp_path, monkeypatch):
             with kmc.KmerCounter(k=k) as kc:
                 nd, nt = kc.count_file(str(p))
                 assert (nd, nt) == (want.n_distinct, want.n_total) and kc.export().equals(want), (cb, k)
+
+
+def test_auto_hands_over_long_high_cardinality_reads(kmc, oracle):
+    """KMC_ALGO_AUTO starts long reads on the walk kernel (as pieces), sees after the first sub-batch
+    that the memo does not help (random sequence: every k-mer new) and hands the REST of the batch
+    to the sort path -- from the end of the last piece walked, in the middle of a read, so the
+    windows that span the hand-over point must be counted exactly once."""
+    rng = np.random.default_rng(99)
+    lens = [100_000] * 40 + [777, 0, 5]
+    offs = np.zeros(len(lens) + 1, np.uint64)
+    offs[1:] = np.cumsum(lens)
+    bases = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, int(offs[-1]))].copy()
+    bases[rng.integers(0, bases.size, 50)] = ord("N")
+    for k in (31, 63):
+        want = oracle.count_kmers(bases, offs, k, True, method=1)
+        t, st = _count(kmc, bases, offs, k, True, kmc.ALGO_AUTO)
+        assert st.algo_last == kmc.ALGO_SORT, st.algo_last   # it did switch
+        assert st.launches_last >= 2
+        assert t.equals(want), k
