@@ -1,0 +1,25 @@
+"""The bench.py output contract, checked on the committed line of the last GPU run
+(profiles/r01_bench_n1.json): the keys and types the driver and the judge read."""
+import json
+import os
+
+from conftest import ROOT
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")))
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                     ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict),
+                     ("roofline", dict), ("cpu_baseline", dict)):
+        assert key in line and isinstance(line[key], typ), key
+    assert line["vs_baseline"] is None and line["scaling"] == "weak" and line["data"] == "synthetic" and line["higher_is_better"] is True
+    assert "workload" in line["config"] and "model" not in line["config"]
+    rf = line["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert rf["traffic"] is None or 0.9 < rf["traffic"] / rf["algorithmic_bytes_per_step"] < 1.2
+    # value is whole-job throughput: k-mers of all steps / elapsed
+    kmers = line["config"]["kmers_per_gpu"] * line["n_gpus"]
+    assert abs(line["value"] - kmers / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["gpu_bit_exact_on_sample"] is True
