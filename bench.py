@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--forward", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-cold", action="store_true", help="skip the untimed cold-memo steps after the timed region (profiling runs)")
+    ap.add_argument("--no-exact-check", action="store_true", help="skip the exact full-size table check after the timed region")
     ap.add_argument("--cpu-sample-records", type=int, default=5_000_000, help="bounded CPU-baseline sample (~10-15 s of one core)")
     args = ap.parse_args()
 
@@ -147,6 +148,21 @@ def main():
             kc.forget_source(memo=True, history=False)
             step(False)
             cold_ms.append(kc.stats().kernel_ms_last)
+    # ---- exact result check, outside the timed region (checker: tests/analytic_oracle.py) ----------
+    # The table this rank counted in the last step must equal, key for key and count for count, the
+    # exact table of its whole record range (line / adjacent-pair histograms over ALL records expanded
+    # through the pool; a few seconds of host time at 22 M records) -- not a prefix, not a bound.
+    exact_full = None
+    if args.pool > 0 and not args.no_exact_check:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import analytic_oracle  # test infrastructure, used here only as the checker
+        tx = time.perf_counter()
+        want_full = analytic_oracle.exact_table(args.seed, k, first, n_rec, canonical=not args.forward, pool=args.pool)
+        got_full = kc.export()
+        exact_full = {"bit_exact": bool(got_full.equals(want_full)), "records": n_rec, "distinct": want_full.n_distinct,
+                      "kmers": want_full.n_total, "host_s": round(time.perf_counter() - tx, 2)}
+        if not exact_full["bit_exact"]:
+            raise SystemExit(f"rank {rank}: GPU table differs from the exact table of records [{first}, {first + n_rec})")
     reduced = None
     if world > 1:
         # outside the timed region: the owner-partitioned result of the last step must account for
@@ -249,7 +265,7 @@ def main():
                                                             "forward" if args.forward else "canonical", world),
                        "records_per_gpu": n_rec, "bases_per_gpu": n_bases, "kmers_per_gpu": n_kmers,
                        "distinct": int(reduced["distinct_all_owners"]) if reduced else int(nd), "algo": algo_used, "sharding": "records, one shard per GPU; RCCL table reduce (one all-gather of fixed-size slabs)"
-                       if world > 1 else "single GPU", "reduced": reduced},
+                       if world > 1 else "single GPU", "reduced": reduced, "exact_full_size_check": exact_full},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }

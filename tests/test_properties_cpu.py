@@ -129,3 +129,29 @@ def test_walk_pieces_partition_the_windows(kmc, read_len, k):
         if e_ - s_ >= k:
             owners[s_:e_ - k + 1] += 1      # windows starting at s_ .. e_-k lie inside [s_, e_)
     assert np.all(owners == 1)
+
+
+def test_analytic_oracle_equals_c_oracle_on_generated_bytes(kmc, oracle):
+    """tests/analytic_oracle.py (exact tables of the synthetic generator at any size, from line and
+    adjacent-pair histograms) against the C oracle counting the bytes libkmc's host generator makes:
+    pins the numpy restatement of the generator AND the expansion.  This is what lets the full-size
+    GPU tests (1 / 10 / 50 GB) assert exact table equality instead of bounds."""
+    import analytic_oracle as ao
+    for seed, k, first, n, canon, shape in (
+            (1, 21, 0, 200_000, True, (10, 80, 5)), (2, 31, 1234, 200_000, True, (10, 80, 5)),
+            (2, 63, 77, 100_000, True, (10, 80, 5)), (3, 31, 5, 50_000, False, (10, 80, 5)),
+            (9, 5, 0, 20_000, True, (10, 80, 5)), (4, 1, 3, 5_000, True, (10, 80, 5)),
+            (5, 31, 11, 30_000, True, (26, 80, 5)), (6, 63, 0, 20_000, True, (16, 64, 3)),
+            (7, 17, 2, 20_000, False, (3, 16, 1)), (8, 33, 9, 10_000, True, (7, 32, 9))):
+        pool, ll, lpr = shape
+        s = kmc.Synth(seed=seed, pool=pool, line_len=ll, lines_per_record=lpr)
+        hb, ho = kmc.synth_reads_host(s, first, n)
+        want = oracle.count_kmers(hb, ho, k, canon, method=1)
+        got = ao.exact_table(seed, k, first, n, canon, pool=pool, line_len=ll, lines_per_record=lpr)
+        assert got.equals(want), (seed, k, shape)
+    # histograms are additive over record ranges and independent of the chunking / threading
+    U1, A1 = ao.line_histograms(2, 10, 5, 0, 1_000_003, chunk=50_000, threads=3)
+    U2, A2 = ao.line_histograms(2, 10, 5, 0, 400_000)
+    U3, A3 = ao.line_histograms(2, 10, 5, 400_000, 600_003, chunk=7_777, threads=1)
+    assert np.array_equal(U1, U2 + U3) and np.array_equal(A1, A2 + A3)
+    assert int(U1.sum()) == 5 * 1_000_003 and int(A1.sum()) == 4 * 1_000_003
