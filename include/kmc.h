@@ -66,6 +66,20 @@ typedef enum kmc_algo {
     KMC_ALGO_SORT = 3    /* extract every window, device radix sort, run-length (high-cardinality input) */
 } kmc_algo;
 
+/* Deviations from the config sketched in SURVEY.md 8b (`n_devices`, `device_ids*`, `backend`), on purpose:
+ *   - ONE `device` per ctx instead of n_devices/device_ids: a ctx is one GPU's table and stream.  Several
+ *     GPUs of one process = several ctxs handed to kmc_count_file_multi (the CLI's --gpus N); scaling
+ *     runs use one process per GPU and RCCL (kmc_pack_slab_device / kmc_merge_slabs_device /
+ *     kmc_partition_device are the device-side halves of that reduce).
+ *   - no `backend` field and no `--backend cpu`: the library has no CPU path to select (kmc_create
+ *     fails with KMC_ERR_NO_DEVICE instead); the CPU restatement lives in oracle/ as test infrastructure.
+ *   - `algo` and `stream` are additions (kernel choice for measurements; running on the caller's stream so
+ *     that kernels and collectives are ordered on the device).
+ * Alphabet rule of KMC_MODE_LR: the reference panics on a character outside ACGT that its bucket_sort
+ * inspects (main.rs:17-23: chunk indices 1..53 of every emitted chunk).  Here KMC_ERR_ALPHABET is raised
+ * for such a byte at ANY index of an emitted chunk (index 0 too: a 2-bit key cannot hold it); bytes no
+ * window reads -- reads shorter than 80 bases, the uncovered middle of reads of 80..105 bases -- are
+ * accepted, as in the reference.  KMC_MODE_CONTIG skips windows that contain such a byte (8a-def). */
 typedef struct kmc_config {
     uint32_t struct_size;   /* = sizeof(kmc_config) */
     int32_t  k;             /* 1..63 in KMC_MODE_CONTIG; ignored in KMC_MODE_LR */
@@ -93,6 +107,8 @@ typedef struct kmc_stats {
     int32_t  algo_last;       /* kmc_algo actually used for the last batch */
     int32_t  launches_last;   /* count-kernel launches in the last batch */
     uint64_t n_slabs_skipped; /* oversize slabs seen by kmc_merge_slabs_device (valid after kmc_finalize) */
+    uint64_t n_direct;        /* k-mers the WALK / STREAM kernels counted with one global atomic each because their
+                                 LDS memo / partial table was full (valid after kmc_finalize / kmc_poll) */
 } kmc_stats;
 
 const char* kmc_version(void);

@@ -51,7 +51,7 @@ class Stats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_kmers", C.c_uint64), ("n_distinct", C.c_uint64),
                 ("table_capacity", C.c_uint64), ("n_spilled", C.c_uint64), ("n_batches", C.c_uint64),
                 ("kernel_ms_last", C.c_double), ("kernel_ms_total", C.c_double), ("algo_last", C.c_int32),
-                ("launches_last", C.c_int32), ("n_slabs_skipped", C.c_uint64)]
+                ("launches_last", C.c_int32), ("n_slabs_skipped", C.c_uint64), ("n_direct", C.c_uint64)]
 
 
 class _Reads(C.Structure):

@@ -31,7 +31,7 @@
 
 namespace {
 
-thread_local std::string g_create_err;
+thread_local char g_create_err[512] = {0};
 
 struct DevBuf {
     void* p = nullptr;
@@ -51,7 +51,7 @@ struct kmc_ctx {
     int klen = 0;   // characters per key (k, or 54 in LR mode)
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    std::string err;
+    char err[512] = {0};
 
     Table tab;
     u64* d_counters = nullptr;      // KMC_CTR_N u64
@@ -103,12 +103,12 @@ struct kmc_ctx {
 namespace {
 
 int fail(kmc_ctx* c, int code, const char* fmt, ...) {
-    char buf[512];
+    char buf[512] = {0};
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof(buf), fmt, ap);
     va_end(ap);
-    if (c) c->err = buf; else g_create_err = buf;
+    memcpy(c ? c->err : g_create_err, buf, sizeof(buf));
     return code;
 }
 
@@ -244,6 +244,7 @@ int poll(kmc_ctx* c) {
     c->batch_pending = false;
     c->unpolled_adds = 0;
     c->st.n_slabs_skipped = c->h_counters[KMC_CTR_SLABSKIP];
+    c->st.n_direct = c->h_counters[KMC_CTR_BADBASE];
     {
         // share of k-mers the walk kernel had to count directly since the previous poll
         u64 d = c->h_counters[KMC_CTR_BADBASE], n = c->h_counters[KMC_CTR_KMERS];
@@ -807,7 +808,7 @@ extern "C" const char* kmc_status_string(int s) {
     }
 }
 
-extern "C" const char* kmc_last_error(const kmc_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+extern "C" const char* kmc_last_error(const kmc_ctx* ctx) { return ctx ? ctx->err : g_create_err; }
 
 extern "C" void kmc_destroy(kmc_ctx* c) {
     if (!c) return;
@@ -824,7 +825,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
                       &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo, &c->vr_reads, &c->vr_cnt, &c->vr_pos,
                       &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->s_flags, &c->s_pos, &c->s_head};
-    free_runs(c, true);
+    try { free_runs(c, true); } catch (...) { /* (only the pool bookkeeping can throw; the buffers it could not list leak with the process) */ }
     for (DevBuf* b : bufs) free_buf(*b);
     for (hipEvent_t e : c->lev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -833,7 +834,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     delete c;
 }
 
-extern "C" int kmc_create(kmc_ctx** out, const kmc_config* cfg) {
+static int kmc_create_impl(kmc_ctx** out, const kmc_config* cfg) {
     if (!out || !cfg) return fail(nullptr, KMC_ERR_ARG, "null argument");
     *out = nullptr;
     if (cfg->struct_size != sizeof(kmc_config)) return fail(nullptr, KMC_ERR_ARG, "kmc_config.struct_size mismatch (%u != %zu)", cfg->struct_size, sizeof(kmc_config));
@@ -879,7 +880,7 @@ extern "C" int kmc_create(kmc_ctx** out, const kmc_config* cfg) {
     };
     rc = body();
     if (rc) {
-        g_create_err = c->err;
+        memcpy(g_create_err, c->err, sizeof(g_create_err));
         kmc_destroy(c);
         return rc;
     }
@@ -887,7 +888,7 @@ extern "C" int kmc_create(kmc_ctx** out, const kmc_config* cfg) {
     return KMC_OK;
 }
 
-extern "C" int kmc_reset(kmc_ctx* c) {
+static int kmc_reset_impl(kmc_ctx* c) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     {
@@ -913,7 +914,7 @@ extern "C" int kmc_reset(kmc_ctx* c) {
     return KMC_OK;
 }
 
-extern "C" int kmc_add_batch_device(kmc_ctx* c, const void* d_bases, const void* d_offsets, uint64_t n_reads,
+static int kmc_add_batch_device_impl(kmc_ctx* c, const void* d_bases, const void* d_offsets, uint64_t n_reads,
                                     uint64_t n_bases, uint64_t max_read_len) {
     if (!c) return KMC_ERR_ARG;
     if (n_reads && (!d_bases || !d_offsets)) return fail(c, KMC_ERR_ARG, "null device pointer");
@@ -923,7 +924,7 @@ extern "C" int kmc_add_batch_device(kmc_ctx* c, const void* d_bases, const void*
     return count_batch_device(c, (const uint8_t*)d_bases, (const u64*)d_offsets, n_reads, n_bases, max_read_len);
 }
 
-extern "C" int kmc_add_batch(kmc_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads) {
+static int kmc_add_batch_impl(kmc_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads) {
     if (!c) return KMC_ERR_ARG;
     if (!n_reads) { c->st.n_batches += 1; return KMC_OK; }
     if (!bases || !offsets) return fail(c, KMC_ERR_ARG, "null buffer");
@@ -946,7 +947,7 @@ extern "C" int kmc_add_batch(kmc_ctx* c, const uint8_t* bases, const uint64_t* o
     return count_batch_device(c, (const uint8_t*)c->st_bases.p, (const u64*)c->st_offsets.p, n_reads, n_bases, maxlen);
 }
 
-extern "C" int kmc_merge_pairs_device(kmc_ctx* c, const void* d_key_hi, const void* d_key_lo, const void* d_count, uint64_t n) {
+static int kmc_merge_pairs_device_impl(kmc_ctx* c, const void* d_key_hi, const void* d_key_lo, const void* d_count, uint64_t n) {
     if (!c) return KMC_ERR_ARG;
     if (!n) return KMC_OK;
     if (!d_key_lo || !d_count) return fail(c, KMC_ERR_ARG, "null device pointer");
@@ -996,7 +997,7 @@ static int sort_view(kmc_ctx* c, u64 n) {
     return KMC_OK;
 }
 
-extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total) {
+static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc;
@@ -1124,7 +1125,7 @@ extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total)
     return KMC_OK;
 }
 
-extern "C" int kmc_export(kmc_ctx* c, uint64_t* key_hi, uint64_t* key_lo, uint64_t* count, uint64_t cap) {
+static int kmc_export_impl(kmc_ctx* c, uint64_t* key_hi, uint64_t* key_lo, uint64_t* count, uint64_t cap) {
     if (!c) return KMC_ERR_ARG;
     if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_export before kmc_finalize");
     const u64 n = c->n_sorted;
@@ -1142,7 +1143,7 @@ extern "C" int kmc_export(kmc_ctx* c, uint64_t* key_hi, uint64_t* key_lo, uint64
     return KMC_OK;
 }
 
-extern "C" int kmc_export_device(kmc_ctx* c, const void** d_key_hi, const void** d_key_lo, const void** d_count, uint64_t* n_distinct) {
+static int kmc_export_device_impl(kmc_ctx* c, const void** d_key_hi, const void** d_key_lo, const void** d_count, uint64_t* n_distinct) {
     if (!c) return KMC_ERR_ARG;
     if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_export_device before kmc_finalize");
     if (d_key_hi) *d_key_hi = c->KW == 2 ? c->v_hi : nullptr;
@@ -1154,7 +1155,7 @@ extern "C" int kmc_export_device(kmc_ctx* c, const void** d_key_hi, const void**
 
 extern "C" uint32_t kmc_owner_of(uint64_t key_hi, uint64_t key_lo, uint32_t n_parts) { return kmc_owner(key_hi, key_lo, n_parts); }
 
-extern "C" int kmc_partition_device(kmc_ctx* c, uint32_t n_parts, uint64_t* part_begin, const void** d_key_hi,
+static int kmc_partition_device_impl(kmc_ctx* c, uint32_t n_parts, uint64_t* part_begin, const void** d_key_hi,
                                     const void** d_key_lo, const void** d_count) {
     if (!c || !n_parts || !part_begin) return KMC_ERR_ARG;
     if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_partition_device before kmc_finalize");
@@ -1198,7 +1199,7 @@ extern "C" uint64_t kmc_slab_words(const kmc_ctx* c, uint64_t slab_entries) {
     return c ? KMC_SLAB_HEADER + slab_entries * (u64)(c->KW + 1) : 0;
 }
 
-extern "C" int kmc_pack_slab_device(kmc_ctx* c, void* d_slab, uint64_t slab_entries) {
+static int kmc_pack_slab_device_impl(kmc_ctx* c, void* d_slab, uint64_t slab_entries) {
     if (!c || !d_slab || !slab_entries) return c ? fail(c, KMC_ERR_ARG, "kmc_pack_slab_device: null slab or zero capacity") : KMC_ERR_ARG;
     if (((uintptr_t)d_slab & 7) != 0) return fail(c, KMC_ERR_ARG, "d_slab must be 8-byte aligned");
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -1220,7 +1221,7 @@ extern "C" int kmc_pack_slab_device(kmc_ctx* c, void* d_slab, uint64_t slab_entr
     return KMC_OK;
 }
 
-extern "C" int kmc_merge_slabs_device(kmc_ctx* c, const void* d_slabs, uint32_t n_slabs, uint64_t slab_entries,
+static int kmc_merge_slabs_device_impl(kmc_ctx* c, const void* d_slabs, uint32_t n_slabs, uint64_t slab_entries,
                                       uint32_t my_part, uint32_t n_parts) {
     if (!c) return KMC_ERR_ARG;
     if (!d_slabs || !n_slabs || !slab_entries || !n_parts || my_part >= n_parts) return fail(c, KMC_ERR_ARG, "kmc_merge_slabs_device: bad argument");
@@ -1258,7 +1259,7 @@ extern "C" uint64_t kmc_read_pieces(uint64_t read_len, int k, uint64_t* starts, 
     return n;
 }
 
-extern "C" int kmc_poll(kmc_ctx* c) {
+static int kmc_poll_impl(kmc_ctx* c) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc = poll_and_settle(c);
@@ -1268,7 +1269,7 @@ extern "C" int kmc_poll(kmc_ctx* c) {
     return KMC_OK;
 }
 
-extern "C" int kmc_forget_source(kmc_ctx* c, int what) {
+static int kmc_forget_source_impl(kmc_ctx* c, int what) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if ((what & KMC_FORGET_MEMO) && c->walk_memo.p) {
@@ -1284,7 +1285,7 @@ extern "C" int kmc_forget_source(kmc_ctx* c, int what) {
     return KMC_OK;
 }
 
-extern "C" int kmc_get_stats(const kmc_ctx* c, kmc_stats* out) {
+static int kmc_get_stats_impl(const kmc_ctx* c, kmc_stats* out) {
     if (!c || !out) return KMC_ERR_ARG;
     harvest_timing(const_cast<kmc_ctx*>(c));  // (kernel_ms_* of a batch that has finished since the last call)
     *out = c->st;
@@ -1297,16 +1298,9 @@ static int count_file_whole(kmc_ctx* c, const char* path, uint64_t* n_distinct, 
     char eb[256] = {0};
     int rc = kmc_parse_fasta(path, &rd, eb, sizeof(eb));
     if (rc) return fail(c, rc, "%s: %s", path, eb);
-    if (c->cfg.mode == KMC_MODE_LR) {
-        // the reference aborts on any non-ACGT character (main.rs:23)
-        for (u64 i = 0; i < rd.n_bases; ++i) {
-            uint8_t b = rd.bases[i];
-            if (b != 'A' && b != 'C' && b != 'G' && b != 'T') {
-                kmc_free_reads(&rd);
-                return fail(c, KMC_ERR_ALPHABET, "Unexpected charactor %c appears", b);
-            }
-        }
-    }
+    // (LR mode: a byte outside ACGT is found by the kernel, which looks at exactly the bytes the windows
+    // read -- like the reference's bucket_sort, main.rs:17-23, which never sees reads shorter than 80
+    // bases or the bytes no window covers)
     const u64 BATCH = 1ull << 30;
     u64 r0 = 0;
     std::vector<u64> offs;
@@ -1354,7 +1348,6 @@ static int count_file_pipeline(kmc_ctx** ctxs, uint32_t n_ctx, const char* path,
     };
     auto body = [&]() -> int {
         KmcIngestChunk ck;
-        const bool lr = c0->cfg.mode == KMC_MODE_LR;
         for (u64 j = 0;; ++j) {
             kmc_ctx* c = ctxs[j % n_ctx];  // chunks go round-robin over the GPUs
             Pinned& p = pin[(size_t)(j % n_ctx) * 2 + ((j / n_ctx) & 1)];
@@ -1365,9 +1358,8 @@ static int count_file_pipeline(kmc_ctx** ctxs, uint32_t n_ctx, const char* path,
             }
             if (p.busy) { HIPCHK(c, hipEventSynchronize(p.ev)); p.busy = false; }  // its upload two rounds ago has finished
             int r;
-            try { r = ing.next(p.bases, lr, &ck, &err); } catch (const std::bad_alloc&) { return fail(c0, KMC_ERR_NOMEM, "out of memory while parsing %s", path); }
+            try { r = ing.next(p.bases, false, &ck, &err); } catch (const std::bad_alloc&) { return fail(c0, KMC_ERR_NOMEM, "out of memory while parsing %s", path); }
             if (r) return fail(c0, r, "%s: %s", path, err.c_str());
-            if (lr && ck.bad_byte >= 0) return fail(c0, KMC_ERR_ALPHABET, "Unexpected charactor %c appears", ck.bad_byte);  // main.rs:23
             if (ck.n_reads) {
                 if (p.offs_cap < ck.n_reads + 1) {
                     if (p.offs) { HIPCHK(c, hipHostFree(p.offs)); p.offs = nullptr; }
@@ -1377,7 +1369,7 @@ static int count_file_pipeline(kmc_ctx** ctxs, uint32_t n_ctx, const char* path,
                 memcpy(p.offs, ck.offsets.data(), (size_t)(ck.n_reads + 1) * sizeof(u64));
                 // settle the ctx's previous batch first (it may still read the staging buffers; its kernels
                 // finished long ago -- this chunk took longer to parse), then queue upload + count without waiting
-                auto fwd = [&](int code) { if (c != c0) c0->err = c->err; return code; };
+                auto fwd = [&](int code) { if (c != c0) memcpy(c0->err, c->err, sizeof(c0->err)); return code; };
                 if (c->pending) { r = poll_and_settle(c); if (r) return fwd(r); }
                 r = ensure(c, c->st_bases, ck.n_bases + 64);
                 if (r) return fwd(r);
@@ -1403,7 +1395,7 @@ static int count_file_pipeline(kmc_ctx** ctxs, uint32_t n_ctx, const char* path,
         kmc_ctx* c = ctxs[i];
         u64 nd = 0, nt = 0;
         rc = kmc_finalize(c, &nd, &nt);
-        if (rc) { c0->err = c->err; return rc; }
+        if (rc) { memcpy(c0->err, c->err, sizeof(c0->err)); return rc; }
         if (!nd) continue;
         HIPCHK(c0, hipSetDevice(c0->cfg.device));
         const int words = c0->KW + 1;
@@ -1428,7 +1420,7 @@ static int count_file_pipeline(kmc_ctx** ctxs, uint32_t n_ctx, const char* path,
 // host cores into one of two pinned buffers while the GPU uploads and counts chunk j; the reader's
 // per-thread pieces go straight to their dense place in the device buffer, so the host never
 // stitches or copies the sequence a second time.
-extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
+static int kmc_count_file_impl(kmc_ctx* c, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
     if (!c || !path) return KMC_ERR_ARG;
     return count_file_pipeline(&c, 1, path, n_distinct, n_total);
 }
@@ -1436,7 +1428,7 @@ extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct
 // The same on several GPUs of ONE process (the CLI's --gpus N): chunks go round-robin to the ctxs,
 // each with its own pinned double buffer, and the tables are reduced into ctxs[0] by peer copies.
 // (Scaling runs use one process per GPU and RCCL instead: k-mer-count_amd/distributed.py.)
-extern "C" int kmc_count_file_multi(kmc_ctx** ctxs, uint32_t n_ctx, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
+static int kmc_count_file_multi_impl(kmc_ctx** ctxs, uint32_t n_ctx, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
     if (!ctxs || !n_ctx || !path) return KMC_ERR_ARG;
     for (uint32_t i = 0; i < n_ctx; ++i) {
         if (!ctxs[i]) return KMC_ERR_ARG;
@@ -1447,7 +1439,7 @@ extern "C" int kmc_count_file_multi(kmc_ctx** ctxs, uint32_t n_ctx, const char* 
     return count_file_pipeline(ctxs, n_ctx, path, n_distinct, n_total);
 }
 
-extern "C" int kmc_synth_reads_device(const kmc_synth* s, uint64_t first_record, uint64_t n_records, void* d_bases,
+static int kmc_synth_reads_device_impl(const kmc_synth* s, uint64_t first_record, uint64_t n_records, void* d_bases,
                                       void* d_offsets, int device, void* stream) {
     if (!s || !d_bases || !d_offsets || !s->line_len || !s->lines_per_record) return KMC_ERR_ARG;
     if (hipSetDevice(device) != hipSuccess) return KMC_ERR_NO_DEVICE;
@@ -1473,4 +1465,75 @@ extern "C" int kmc_synth_reads_device(const kmc_synth* s, uint64_t first_record,
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (d_pool) (void)hipFree(d_pool);
     return e == hipSuccess ? KMC_OK : KMC_ERR_HIP;
+}
+
+// ---- the ABI proper: no C++ exception leaves the library (kmc.h: "no exception or abort crosses the ABI") ----
+namespace {
+template <typename F>
+int guarded(kmc_ctx* c, F&& f) noexcept {
+    try {
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail(c, KMC_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception& e) {
+        return fail(c, KMC_ERR_HIP, "internal error: %s", e.what());
+    } catch (...) {
+        return fail(c, KMC_ERR_HIP, "internal error (unknown C++ exception)");
+    }
+}
+}  // namespace
+extern "C" int kmc_create(kmc_ctx** out, const kmc_config* cfg) {
+    return guarded(nullptr, [&]() -> int { return kmc_create_impl(out, cfg); });
+}
+extern "C" int kmc_reset(kmc_ctx* c) {
+    return guarded(c, [&]() -> int { return kmc_reset_impl(c); });
+}
+extern "C" int kmc_add_batch_device(kmc_ctx* c, const void* d_bases, const void* d_offsets, uint64_t n_reads,
+                                    uint64_t n_bases, uint64_t max_read_len) {
+    return guarded(c, [&]() -> int { return kmc_add_batch_device_impl(c, d_bases, d_offsets, n_reads, n_bases, max_read_len); });
+}
+extern "C" int kmc_add_batch(kmc_ctx* c, const uint8_t* bases, const uint64_t* offsets, uint64_t n_reads) {
+    return guarded(c, [&]() -> int { return kmc_add_batch_impl(c, bases, offsets, n_reads); });
+}
+extern "C" int kmc_merge_pairs_device(kmc_ctx* c, const void* d_key_hi, const void* d_key_lo, const void* d_count, uint64_t n) {
+    return guarded(c, [&]() -> int { return kmc_merge_pairs_device_impl(c, d_key_hi, d_key_lo, d_count, n); });
+}
+extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total) {
+    return guarded(c, [&]() -> int { return kmc_finalize_impl(c, n_distinct, n_total); });
+}
+extern "C" int kmc_export(kmc_ctx* c, uint64_t* key_hi, uint64_t* key_lo, uint64_t* count, uint64_t cap) {
+    return guarded(c, [&]() -> int { return kmc_export_impl(c, key_hi, key_lo, count, cap); });
+}
+extern "C" int kmc_export_device(kmc_ctx* c, const void** d_key_hi, const void** d_key_lo, const void** d_count, uint64_t* n_distinct) {
+    return guarded(c, [&]() -> int { return kmc_export_device_impl(c, d_key_hi, d_key_lo, d_count, n_distinct); });
+}
+extern "C" int kmc_partition_device(kmc_ctx* c, uint32_t n_parts, uint64_t* part_begin, const void** d_key_hi,
+                                    const void** d_key_lo, const void** d_count) {
+    return guarded(c, [&]() -> int { return kmc_partition_device_impl(c, n_parts, part_begin, d_key_hi, d_key_lo, d_count); });
+}
+extern "C" int kmc_pack_slab_device(kmc_ctx* c, void* d_slab, uint64_t slab_entries) {
+    return guarded(c, [&]() -> int { return kmc_pack_slab_device_impl(c, d_slab, slab_entries); });
+}
+extern "C" int kmc_merge_slabs_device(kmc_ctx* c, const void* d_slabs, uint32_t n_slabs, uint64_t slab_entries,
+                                      uint32_t my_part, uint32_t n_parts) {
+    return guarded(c, [&]() -> int { return kmc_merge_slabs_device_impl(c, d_slabs, n_slabs, slab_entries, my_part, n_parts); });
+}
+extern "C" int kmc_poll(kmc_ctx* c) {
+    return guarded(c, [&]() -> int { return kmc_poll_impl(c); });
+}
+extern "C" int kmc_forget_source(kmc_ctx* c, int what) {
+    return guarded(c, [&]() -> int { return kmc_forget_source_impl(c, what); });
+}
+extern "C" int kmc_get_stats(const kmc_ctx* c, kmc_stats* out) {
+    return guarded(const_cast<kmc_ctx*>(c), [&]() -> int { return kmc_get_stats_impl(c, out); });
+}
+extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
+    return guarded(c, [&]() -> int { return kmc_count_file_impl(c, path, n_distinct, n_total); });
+}
+extern "C" int kmc_count_file_multi(kmc_ctx** ctxs, uint32_t n_ctx, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
+    return guarded((ctxs && n_ctx ? ctxs[0] : nullptr), [&]() -> int { return kmc_count_file_multi_impl(ctxs, n_ctx, path, n_distinct, n_total); });
+}
+extern "C" int kmc_synth_reads_device(const kmc_synth* s, uint64_t first_record, uint64_t n_records, void* d_bases,
+                                      void* d_offsets, int device, void* stream) {
+    return guarded(nullptr, [&]() -> int { return kmc_synth_reads_device_impl(s, first_record, n_records, d_bases, d_offsets, device, stream); });
 }

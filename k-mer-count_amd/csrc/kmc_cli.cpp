@@ -14,6 +14,7 @@
 //   -k K    count-table mode: contiguous canonical K-mers, "KMER<TAB>COUNT" lines sorted by KMER
 //
 // Errors: message on stderr, exit code 101 (what a Rust panic exits with), never partial stdout.
+#include <errno.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,23 +29,40 @@ static int die(const char* what, const char* msg) {
     return 101;
 }
 
+// a whole decimal number in [lo, hi], or exit code 2 (atoi turned "-k abc" and "-k 0" into the
+// reference's LR mode and printed 195 MB instead of an error)
+static bool parse_int(const char* opt, const char* text, long lo, long hi, int* out) {
+    char* end = nullptr;
+    errno = 0;
+    const long v = strtol(text, &end, 10);
+    if (errno || end == text || *end != '\0' || v < lo || v > hi) {
+        fprintf(stderr, "k-mer-count: %s needs a whole number in %ld..%ld (got '%s')\n", opt, lo, hi, text);
+        return false;
+    }
+    *out = (int)v;
+    return true;
+}
+
 int main(int argc, char** argv) {
     const char* path = "sample.fasta";  // main.rs:44
     int k = 0, canonical = 1, expand = 0, device = 0, algo = KMC_ALGO_AUTO, stats = 0, gpus = 1;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
-        if (a == "-k" && i + 1 < argc) k = atoi(argv[++i]);
+        if (a == "-k" && i + 1 < argc) { if (!parse_int("-k", argv[++i], 1, 63, &k)) return 2; }
         else if (a == "--forward") canonical = 0;
         else if (a == "--expand") expand = 1;
         else if (a == "--stats") stats = 1;
-        else if (a == "--device" && i + 1 < argc) device = atoi(argv[++i]);
-        else if (a == "--gpus" && i + 1 < argc) gpus = atoi(argv[++i]);
+        else if (a == "--device" && i + 1 < argc) { if (!parse_int("--device", argv[++i], 0, 1023, &device)) return 2; }
+        else if (a == "--gpus" && i + 1 < argc) { if (!parse_int("--gpus", argv[++i], 1, 64, &gpus)) return 2; }
         else if (a == "--algo" && i + 1 < argc) {
             std::string v = argv[++i];
             algo = v == "stream" ? KMC_ALGO_STREAM : v == "walk" ? KMC_ALGO_WALK : v == "sort" ? KMC_ALGO_SORT : KMC_ALGO_AUTO;
         } else if (a == "-h" || a == "--help") {
             fprintf(stderr, "usage: k-mer-count [FASTA] [-k K] [--forward] [--expand] [--device N | --gpus N] [--algo auto|stream|walk|sort] [--stats]\n");
             return 0;
+        } else if (a == "-k" || a == "--device" || a == "--gpus" || a == "--algo") {
+            fprintf(stderr, "k-mer-count: %s needs a value\n", a.c_str());
+            return 2;
         } else if (!a.empty() && a[0] != '-') path = argv[i];
         else { fprintf(stderr, "k-mer-count: unknown option %s\n", a.c_str()); return 2; }
     }

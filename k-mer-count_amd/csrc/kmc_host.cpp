@@ -30,6 +30,17 @@ void set_err(char* errbuf, size_t n, const char* msg) {
     if (errbuf && n) { snprintf(errbuf, n, "%s", msg); }
 }
 
+// Worker threads that are joined on EVERY way out of a scope: if starting the i-th thread throws
+// (std::system_error: no resources), unwinding must not destroy joinable threads -- that would be
+// std::terminate, i.e. an abort across the C ABI (kmc.h promises a status code instead).
+struct ThreadGroup {
+    std::vector<std::thread> th;
+    explicit ThreadGroup(size_t n) { th.reserve(n); }  // (so that emplace_back never reallocates)
+    template <typename... A> void start(A&&... a) { th.emplace_back(std::forward<A>(a)...); }
+    void join() { for (auto& t : th) if (t.joinable()) t.join(); }
+    ~ThreadGroup() { join(); }
+};
+
 }  // namespace
 
 // Multi-threaded reader.  The file is cut into byte segments; every worker snaps its segment to
@@ -47,9 +58,16 @@ struct SegOut {
     int err = 0;
 };
 
+void parse_segment_body(const char* path, uint64_t begin, uint64_t end, uint64_t fsize, bool first, SegOut* out);
+// thread entry: an exception leaving a thread function is std::terminate
 void parse_segment(const char* path, uint64_t begin, uint64_t end, uint64_t fsize, bool first, SegOut* out) {
+    try { parse_segment_body(path, begin, end, fsize, first, out); } catch (...) { out->err = KMC_ERR_NOMEM; }
+}
+void parse_segment_body(const char* path, uint64_t begin, uint64_t end, uint64_t fsize, bool first, SegOut* out) {
+    struct FileCloser { FILE* f; ~FileCloser() { if (f) fclose(f); } };
     FILE* f = fopen(path, "rb");
     if (!f) { out->err = KMC_ERR_IO; return; }
+    FileCloser closer{f};
     // snap `begin` to the first line start >= begin (unless it is the file start)
     const size_t BUF = 1u << 22;
     std::vector<char> buf(BUF);
@@ -65,9 +83,9 @@ void parse_segment(const char* path, uint64_t begin, uint64_t end, uint64_t fsiz
             const char* nl = (const char*)memchr(buf.data(), '\n', got);
             if (nl) { pos += (uint64_t)(nl - buf.data()) + 1; found = true; } else pos += got;
         }
-        if (!found) { fclose(f); return; }  // no line starts in this segment
+        if (!found) return;  // no line starts in this segment
     }
-    if (pos >= end && !(first && fsize == 0)) { if (pos >= end) { fclose(f); return; } }
+    if (pos >= end) return;
     fseeko(f, (off_t)pos, SEEK_SET);
     out->seq.reserve((size_t)(end > pos ? end - pos : 0) + 64);
     std::string carry;  // a line cut by the read buffer
@@ -107,7 +125,6 @@ void parse_segment(const char* path, uint64_t begin, uint64_t end, uint64_t fsiz
         }
     }
     if (!stop && !carry.empty()) handle_line(carry.data(), carry.size(), line_start);  // last line without '\n'
-    fclose(f);
 }
 
 }  // namespace
@@ -124,13 +141,14 @@ extern "C" int kmc_parse_fasta(const char* path, kmc_reads* out, char* errbuf, s
         unsigned hw = std::thread::hardware_concurrency();
         uint64_t nseg = std::min<uint64_t>(std::max(1u, std::min(hw, 32u)), std::max<uint64_t>(1, fsize >> 24));  // >= 16 MiB each
         std::vector<SegOut> segs((size_t)nseg);
-        std::vector<std::thread> th;
-        for (uint64_t i = 0; i < nseg; ++i) {
-            uint64_t b = fsize * i / nseg, e = fsize * (i + 1) / nseg;
-            th.emplace_back(parse_segment, path, b, e, fsize, i == 0, &segs[(size_t)i]);
+        {
+            ThreadGroup th((size_t)nseg);
+            for (uint64_t i = 0; i < nseg; ++i) {
+                uint64_t b = fsize * i / nseg, e = fsize * (i + 1) / nseg;
+                th.start(parse_segment, path, b, e, fsize, i == 0, &segs[(size_t)i]);
+            }
         }
-        for (auto& t : th) t.join();
-        for (auto& sg : segs) if (sg.err) { set_err(errbuf, errbuf_len, "Error during opening the file"); return sg.err; }
+        for (auto& sg : segs) if (sg.err) { set_err(errbuf, errbuf_len, sg.err == KMC_ERR_NOMEM ? "out of memory" : "Error during opening the file"); return sg.err; }
         if (segs[0].bad_first_line) { set_err(errbuf, errbuf_len, "Expected > at record start."); return KMC_ERR_FORMAT; }
         // stitch
         uint64_t total = 0, nrec = 0;
@@ -145,13 +163,14 @@ extern "C" int kmc_parse_fasta(const char* path, kmc_reads* out, char* errbuf, s
         }
         std::vector<uint8_t> blank((size_t)nrec);
         uint64_t base = 0, r = 0;
-        std::vector<std::thread> cp;
-        for (auto& sg : segs) {
-            for (size_t j = 0; j < sg.rec_start.size(); ++j) { out->offsets[r] = base + sg.rec_start[j]; blank[(size_t)r] = sg.rec_blank[j]; r++; }
-            if (!sg.seq.empty()) cp.emplace_back([dst = out->bases + base, &sg]() { memcpy(dst, sg.seq.data(), sg.seq.size()); });
-            base += sg.seq.size();
+        {
+            ThreadGroup cp(segs.size());
+            for (auto& sg : segs) {
+                for (size_t j = 0; j < sg.rec_start.size(); ++j) { out->offsets[r] = base + sg.rec_start[j]; blank[(size_t)r] = sg.rec_blank[j]; r++; }
+                if (!sg.seq.empty()) cp.start([dst = out->bases + base, &sg]() { memcpy(dst, sg.seq.data(), sg.seq.size()); });
+                base += sg.seq.size();
+            }
         }
-        for (auto& t : cp) t.join();
         out->offsets[nrec] = total;
         // Record::is_empty(): a record with empty header and no sequence ends the input (main.rs:60-62)
         uint64_t keep = nrec;
@@ -174,6 +193,11 @@ extern "C" int kmc_parse_fasta(const char* path, kmc_reads* out, char* errbuf, s
         memset(out, 0, sizeof(*out));
         set_err(errbuf, errbuf_len, "cannot start parser threads");
         return KMC_ERR_NOMEM;
+    } catch (...) {
+        free(out->bases); free(out->offsets);
+        memset(out, 0, sizeof(*out));
+        set_err(errbuf, errbuf_len, "internal error in the FASTA reader");
+        return KMC_ERR_NOMEM;
     }
 }
 
@@ -188,6 +212,7 @@ extern "C" int kmc_parse_fasta(const char* path, kmc_reads* out, char* errbuf, s
 namespace {
 
 struct PieceOut {
+    bool oom = false;  // the worker ran out of memory (an exception must not leave a thread function)
     uint64_t src_off = 0, n_bytes = 0;
     std::vector<uint64_t> rec_start;  // local: sequence bytes of this piece that precede the record
     std::vector<uint8_t> rec_blank;
@@ -196,7 +221,11 @@ struct PieceOut {
 };
 
 // lines of text[b, e) (b is a line start; the last line may end at e without '\n')
+void parse_piece_body(const char* text, uint64_t b, uint64_t e, bool file_start, bool check_alphabet, uint8_t* out, PieceOut* po);
 void parse_piece(const char* text, uint64_t b, uint64_t e, bool file_start, bool check_alphabet, uint8_t* out, PieceOut* po) {
+    try { parse_piece_body(text, b, e, file_start, check_alphabet, out, po); } catch (...) { po->oom = true; }
+}
+void parse_piece_body(const char* text, uint64_t b, uint64_t e, bool file_start, bool check_alphabet, uint8_t* out, PieceOut* po) {
     const char* p = text + b;
     const char* const end = text + e;
     uint8_t* o = out;
@@ -231,7 +260,11 @@ void parse_piece(const char* text, uint64_t b, uint64_t e, bool file_start, bool
 }
 
 // four-line FASTQ records of text[b, e) (b is a record start)
+void parse_piece_fastq_body(const char* text, uint64_t b, uint64_t e, bool check_alphabet, uint8_t* out, PieceOut* po);
 void parse_piece_fastq(const char* text, uint64_t b, uint64_t e, bool check_alphabet, uint8_t* out, PieceOut* po) {
+    try { parse_piece_fastq_body(text, b, e, check_alphabet, out, po); } catch (...) { po->oom = true; }
+}
+void parse_piece_fastq_body(const char* text, uint64_t b, uint64_t e, bool check_alphabet, uint8_t* out, PieceOut* po) {
     const char* p = text + b;
     const char* const end = text + e;
     uint8_t* o = out;
@@ -362,19 +395,19 @@ int KmcFastaIngest::next(uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* 
     sb[(size_t)nseg] = ce;
     std::vector<PieceOut> po((size_t)nseg);
     try {
-        std::vector<std::thread> th;
+        ThreadGroup th((size_t)nseg);  // joined on every way out, also when starting a thread throws
         for (uint64_t i = 1; i < nseg; ++i) {
             po[(size_t)i].src_off = sb[(size_t)i] - cb;
-            if (fastq_) th.emplace_back(parse_piece_fastq, map_, sb[(size_t)i], sb[(size_t)i + 1], check_alphabet, out_buf + po[(size_t)i].src_off, &po[(size_t)i]);
-            else th.emplace_back(parse_piece, map_, sb[(size_t)i], sb[(size_t)i + 1], false, check_alphabet, out_buf + po[(size_t)i].src_off, &po[(size_t)i]);
+            if (fastq_) th.start(parse_piece_fastq, map_, sb[(size_t)i], sb[(size_t)i + 1], check_alphabet, out_buf + po[(size_t)i].src_off, &po[(size_t)i]);
+            else th.start(parse_piece, map_, sb[(size_t)i], sb[(size_t)i + 1], false, check_alphabet, out_buf + po[(size_t)i].src_off, &po[(size_t)i]);
         }
         if (fastq_) parse_piece_fastq(map_, sb[0], sb[1], check_alphabet, out_buf, &po[0]);
         else parse_piece(map_, sb[0], sb[1], cb == 0, check_alphabet, out_buf, &po[0]);
-        for (auto& t : th) t.join();
     } catch (const std::system_error&) {
         if (err) *err = "cannot start parser threads";
         return KMC_ERR_NOMEM;
     }
+    for (auto& p : po) if (p.oom) throw std::bad_alloc();  // (callers turn it into KMC_ERR_NOMEM)
     if (fastq_) {
         for (auto& p : po)
             if (p.bad_first_line) { if (err) *err = "malformed FASTQ record (expected '@' header and '+' separator lines)"; done_ = true; return KMC_ERR_FORMAT; }
@@ -432,10 +465,12 @@ extern "C" int kmc_fasta_stream_open(const char* path, uint64_t chunk_bytes, kmc
     *out = nullptr;
     kmc_fasta_stream* s = new (std::nothrow) kmc_fasta_stream();
     if (!s) return KMC_ERR_NOMEM;
-    std::string err;
-    int rc = s->ing.open(path, chunk_bytes ? chunk_bytes : (256ull << 20), &err);
-    if (rc) { set_err(errbuf, errbuf_len, err.c_str()); delete s; return rc; }
-    try { s->buf.resize((size_t)s->ing.chunk_capacity()); } catch (const std::bad_alloc&) { delete s; set_err(errbuf, errbuf_len, "out of memory"); return KMC_ERR_NOMEM; }
+    try {
+        std::string err;
+        int rc = s->ing.open(path, chunk_bytes ? chunk_bytes : (256ull << 20), &err);
+        if (rc) { set_err(errbuf, errbuf_len, err.c_str()); delete s; return rc; }
+        s->buf.resize((size_t)s->ing.chunk_capacity());
+    } catch (...) { delete s; set_err(errbuf, errbuf_len, "out of memory"); return KMC_ERR_NOMEM; }
     *out = s;
     return KMC_OK;
 }
@@ -443,12 +478,12 @@ extern "C" int kmc_fasta_stream_open(const char* path, uint64_t chunk_bytes, kmc
 extern "C" int kmc_fasta_stream_next(kmc_fasta_stream* s, kmc_reads* out, int* eof, char* errbuf, size_t errbuf_len) {
     if (!s || !out) return KMC_ERR_ARG;
     memset(out, 0, sizeof(*out));
-    std::string err;
     int rc;
     try {
+        std::string err;
         rc = s->ing.next(s->buf.data(), false, &s->ck, &err);
-    } catch (const std::bad_alloc&) { set_err(errbuf, errbuf_len, "out of memory"); return KMC_ERR_NOMEM; }
-    if (rc) { set_err(errbuf, errbuf_len, err.c_str()); return rc; }
+        if (rc) { set_err(errbuf, errbuf_len, err.c_str()); return rc; }
+    } catch (...) { set_err(errbuf, errbuf_len, "out of memory"); return KMC_ERR_NOMEM; }
     // dense form: the pieces move left, in order (destination never passes a later piece's source)
     for (auto& pc : s->ck.pieces)
         if (pc.dst_off != pc.src_off) memmove(s->buf.data() + pc.dst_off, s->buf.data() + pc.src_off, (size_t)pc.n_bytes);
@@ -511,7 +546,8 @@ extern "C" int kmc_synth_reads_host(const kmc_synth* s, uint64_t first_record, u
                                     uint8_t* bases, uint64_t* offsets) {
     if (!s || !bases || !offsets || !s->line_len || !s->lines_per_record) return KMC_ERR_ARG;
     const uint64_t read_len = (uint64_t)s->lines_per_record * s->line_len;
-    std::vector<uint8_t> pool((size_t)s->pool * s->line_len);
+    std::vector<uint8_t> pool;
+    try { pool.resize((size_t)s->pool * s->line_len); } catch (...) { return KMC_ERR_NOMEM; }
     for (uint32_t p = 0; p < s->pool; ++p)
         for (uint32_t x = 0; x < s->line_len; ++x) pool[(size_t)p * s->line_len + x] = kmc_synth_pool_base(s->seed, s->line_len, p, x);
     for (uint64_t r = 0; r < n_records; ++r) {
@@ -534,6 +570,7 @@ extern "C" int kmc_synth_write_fasta(const kmc_synth* s, uint64_t first_record, 
     if (!s || !FILE_ptr || !s->line_len || !s->lines_per_record) return KMC_ERR_ARG;
     FILE* f = (FILE*)FILE_ptr;
     const uint64_t read_len = (uint64_t)s->lines_per_record * s->line_len;
+    try {
     std::vector<uint8_t> bases(read_len);
     uint64_t offs[2];
     std::string rec;
@@ -549,5 +586,6 @@ extern "C" int kmc_synth_write_fasta(const kmc_synth* s, uint64_t first_record, 
         }
         if (fwrite(rec.data(), 1, rec.size(), f) != rec.size()) return KMC_ERR_IO;
     }
+    } catch (...) { return KMC_ERR_NOMEM; }
     return KMC_OK;
 }

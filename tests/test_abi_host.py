@@ -290,3 +290,128 @@ def test_host_code_under_sanitizers(kmc, tmp_path):
     files += [SAMPLE, str(tmp_path / "missing.fasta")]
     r = subprocess.run([str(exe)] + files, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1500:], r.stderr[-3000:])
+
+
+# ---- the Rust binding (source only: no rustc in the build environment) checked against the header ----
+_C2R = {"int": "i32", "int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "uint8_t": "u8", "size_t": "usize", "double": "f64",
+        "char": "c_char", "void": "c_void", "kmc_ctx": "KmcCtx", "kmc_config": "KmcConfig", "kmc_stats": "KmcStats",
+        "kmc_reads": "KmcReads", "kmc_synth": "KmcSynth", "kmc_fasta_stream": "KmcFastaStream"}
+
+
+def _c_type_to_rust(t):
+    """'const uint64_t*' -> '*const u64', 'const void**' -> '*mut *const c_void', 'kmc_ctx**' -> '*mut *mut KmcCtx'."""
+    t = t.strip()
+    stars = t.count("*")
+    base = t.replace("*", " ").split()
+    const = "const" in base
+    base = [b for b in base if b != "const"]
+    assert len(base) == 1, t
+    r = _C2R[base[0]]
+    for i in range(stars):
+        r = ("*const " if (const and i == 0) else "*mut ") + r
+    return r
+
+
+def _norm_rust(t):
+    return re.sub(r"\s+", " ", t.strip()).replace("c_int", "i32")
+
+
+def test_rust_binding_matches_the_header():
+    """rust/src/lib.rs cannot be compiled here, so its extern "C" block and #[repr(C)] structs are parsed
+    and compared with include/kmc.h: every declared function is bound, with the same number of
+    arguments, the same argument and return types, and every struct has the same fields in the same order."""
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "kmc.h")).read(), flags=re.S)
+    rs = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "rust", "src", "lib.rs")).read())
+    # functions
+    c_funcs = {}
+    for ret, name, args in re.findall(r"^\s*([A-Za-z_][\w\s\*]*?)\s*\b(kmc_\w+)\s*\(([^)]*)\)\s*;", hdr, flags=re.M):
+        args = [] if args.strip() in ("", "void") else [a.strip() for a in args.split(",")]
+        c_funcs[name] = (ret.strip(), [re.sub(r"\s*\b\w+$", "", a) for a in args])
+    block = re.search(r'extern "C" \{(.*?)\n\}', rs, flags=re.S).group(1)
+    r_funcs = {}
+    for name, args, ret in re.findall(r"pub fn (kmc_\w+)\((.*?)\)\s*(?:->\s*([^;]+))?;", block, flags=re.S):
+        args = [a.strip() for a in args.split(",") if a.strip()]
+        r_funcs[name] = (_norm_rust(ret) if ret else "()", [_norm_rust(a.split(":", 1)[1]) for a in args])
+    assert sorted(c_funcs) == sorted(r_funcs), (sorted(set(c_funcs) ^ set(r_funcs)))
+    for name, (ret, args) in c_funcs.items():
+        want_ret = "()" if ret == "void" else _c_type_to_rust(ret)
+        assert r_funcs[name][0] == want_ret, (name, r_funcs[name][0], want_ret)
+        assert r_funcs[name][1] == [_c_type_to_rust(a) for a in args], (name, r_funcs[name][1], args)
+    # structs
+    for cname, rname in (("kmc_config", "KmcConfig"), ("kmc_stats", "KmcStats"), ("kmc_reads", "KmcReads"), ("kmc_synth", "KmcSynth")):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, flags=re.S).group(1)
+        c_fields = [(m[1], _c_type_to_rust(m[0])) for m in re.findall(r"([\w\s\*]+?)\s*\b(\w+)\s*;", body)]
+        rbody = re.search(r"#\[repr\(C\)\]\s*pub struct %s \{(.*?)\}" % rname, rs, flags=re.S).group(1)
+        r_fields = [(n, _norm_rust(t)) for n, t in re.findall(r"pub (\w+):\s*([^,]+),", rbody)]
+        assert c_fields == r_fields, (cname, c_fields, r_fields)
+    # constants the wrapper uses
+    for cn, val in re.findall(r"^\s*(KMC_(?:MODE|ALGO)_\w+) = (\d+)", hdr, flags=re.M):
+        m = re.search(r"pub const %s: i32 = (\d+);" % cn, rs)
+        assert m and m.group(1) == val, cn
+
+
+def test_host_entry_points_survive_allocation_failure(kmc, tmp_path):
+    """kmc.h: "no exception or abort crosses the ABI".  In a child process the address space is capped
+    (RLIMIT_AS) so that the host readers' allocations fail: every call must come back with a negative
+    status (out of memory / I/O), the process must neither abort nor be killed, and the library must
+    still work once the limit is lifted."""
+    fa = tmp_path / "big.fasta"
+    with open(fa, "wb") as f:
+        subprocess.run([os.path.join(ROOT, "bin", "kmc-genfasta"), "--records", "600000", "--seed", "5"], stdout=f, check=True)
+    assert os.path.getsize(fa) > 250_000_000
+    child = r'''
+import ctypes as C, resource, sys
+L = C.CDLL(sys.argv[1])
+class Reads(C.Structure):
+    _fields_ = [("bases", C.c_void_p), ("offsets", C.c_void_p), ("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("max_read_len", C.c_uint64)]
+L.kmc_parse_fasta.argtypes = [C.c_char_p, C.POINTER(Reads), C.c_char_p, C.c_size_t]
+L.kmc_fasta_stream_open.argtypes = [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]
+L.kmc_fasta_stream_next.argtypes = [C.c_void_p, C.POINTER(Reads), C.POINTER(C.c_int), C.c_char_p, C.c_size_t]
+L.kmc_fasta_stream_close.argtypes = [C.c_void_p]
+L.kmc_free_reads.argtypes = [C.POINTER(Reads)]
+path = sys.argv[2].encode()
+eb = C.create_string_buffer(256)
+def vm():
+    for line in open("/proc/self/status"):
+        if line.startswith("VmSize"):
+            return int(line.split()[1]) * 1024
+soft, hard = resource.getrlimit(resource.RLIMIT_AS)
+results = []
+for extra in (48 << 20, 96 << 20, 160 << 20):
+    resource.setrlimit(resource.RLIMIT_AS, (vm() + extra, hard))
+    rd = Reads()
+    rc = L.kmc_parse_fasta(path, C.byref(rd), eb, 256)
+    results.append(("parse", extra >> 20, rc))
+    if rc == 0: L.kmc_free_reads(C.byref(rd))
+    h = C.c_void_p()
+    rc = L.kmc_fasta_stream_open(path, 64 << 20, C.byref(h), eb, 256)
+    results.append(("open", extra >> 20, rc))
+    if rc == 0:
+        eof = C.c_int(0)
+        while not eof.value:
+            rc = L.kmc_fasta_stream_next(h, C.byref(rd), C.byref(eof), eb, 256)
+            if rc: break
+        results.append(("next", extra >> 20, rc))
+        L.kmc_fasta_stream_close(h)
+    resource.setrlimit(resource.RLIMIT_AS, (soft, hard))
+rd = Reads()
+rc = L.kmc_parse_fasta(path, C.byref(rd), eb, 256)
+results.append(("parse_unlimited", 0, rc, rd.n_reads))
+print(results)
+'''
+    import sys
+    r = subprocess.run([sys.executable, "-c", child, kmc.LIB_PATH, str(fa)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout[-800:], r.stderr[-800:])   # no abort (SIGABRT = -6), no kill
+    results = eval(r.stdout.strip().splitlines()[-1])
+    failures = [x for x in results if x[0] != "parse_unlimited" and x[2] != 0]
+    assert failures, results                                   # the cap did bite somewhere ...
+    assert all(x[2] in (kmc.ERR_NOMEM, kmc.ERR_IO) for x in failures), results   # ... and came back as a status code
+    assert results[-1][2] == 0 and results[-1][3] == 600_000   # and the library is intact afterwards
+
+
+def test_cli_rejects_bad_numbers(kmc):
+    """`-k abc` / `-k 0` must be an error (exit 2), not the reference's LR mode (atoi gave 0 = no -k)."""
+    exe = os.path.join(ROOT, "bin", "k-mer-count")
+    for argv in (["-k", "abc"], ["-k", "0"], ["-k", "64"], ["-k", "31x"], ["-k"], ["--gpus", "0"], ["--device", "-1"]):
+        r = subprocess.run([exe, SAMPLE] + argv, capture_output=True, text=True)
+        assert r.returncode == 2 and r.stdout == "" and "k-mer-count:" in r.stderr, (argv, r.returncode, r.stderr)
