@@ -25,60 +25,155 @@
 #define KMC_STREAM_WAVES (KMC_STREAM_THREADS / 64)
 #define KMC_CHUNK 1024
 
+// LDS partial table of one workgroup.  A slot holds a FORWARD-strand key; the canonical strand is
+// chosen once per distinct key at the flush (counting is additive, so the table is the same as with
+// per-occurrence canonicalisation -- what the walk kernel does too).  Slots are grouped in buckets of
+// two, a key's home bucket is 2 * (hash % NB):
+//   hot path  (once per k-mer, no loop, no CAS): read the two home slots, compare, ds_add on a hit;
+//   miss      (first sight of a key, or a key that did not fit its home bucket): the key is appended
+//             to the wave's miss buffer (one ballot + one LDS store) and the wave moves on;
+//   drain     (once per chunk, or when the buffer fills): 64 buffered keys at a time go through the
+//             probing insert (CAS claim, linear probing over the following slots, global table when
+//             the LDS table is full).
+// The first version of this kernel ran a probing loop per k-mer whose only exit was a wave-wide ballot:
+// with 64 lanes almost every trip had a straggler (190 SALU + 84 VALU wave-instructions per k-mer step,
+// 61 ms on the benchmark batch = 150 GB/s).
+#define KMC_STREAM_MISSBUF 128
+template <int KW> struct StreamSlot;
+template <> struct StreamSlot<1> { u64 lo; };
+template <> struct StreamSlot<2> { u64 lo, hi; };
 template <int KW> struct StreamLds {
-    static constexpr int LCAP = (KW == 1) ? 8192 : 4096;  // 96 KB / 80 KB of keys+counts: one workgroup per CU
-    u64 lo[LCAP];
-    u64 hi[KW == 2 ? LCAP : 1];
+    static constexpr int LCAP = (KW == 1) ? 8192 : 4096;  // slots (64 KB of keys either way): one workgroup per CU
+    static constexpr int LOGNB = (KW == 1) ? 12 : 11;      // log2(buckets of two)
+    StreamSlot<KW> slot[LCAP];
     u32 cnt[LCAP];
+    StreamSlot<KW> miss[KMC_STREAM_WAVES][KMC_STREAM_MISSBUF];
     u32 sbits[KMC_STREAM_WAVES][64];
     u32 nfill;
 };
 
-// insert-or-increment in the workgroup's LDS table; falls through to the global table when the
-// probe budget is exhausted or the table is (nearly) full.  Same wave-uniform loop shape as
-// gtable_add (see there for why).
+// home bucket (index of its first slot).  One 32-bit multiply: the high bits of the product depend on
+// every bit of the folded key.  (The first version used a 64-bit multiplicative mix: four quarter-rate
+// multiplies per k-mer.)
 template <int KW>
-__device__ __forceinline__ bool lds_add(StreamLds<KW>& L, const GTable& g, u64 hi, u64 lo, bool lds_ok) {
+__device__ __forceinline__ u32 stream_home(u64 hi, u64 lo) {
+    u32 a = (u32)lo ^ __builtin_amdgcn_alignbit((u32)(lo >> 32), (u32)(lo >> 32), 21);
+    if (KW == 2) a ^= __builtin_amdgcn_alignbit((u32)hi, (u32)hi, 27) ^ __builtin_amdgcn_alignbit((u32)(hi >> 32), (u32)(hi >> 32), 13);
+    const u32 h = a * 0x9E3779B1u;
+    return (h >> (32 - StreamLds<KW>::LOGNB)) << 1;
+}
+
+template <int KW, bool CANON>
+__device__ __forceinline__ void stream_gadd(const GTable& g, u64 hi, u64 lo, int k, u64 cnt) {
+    if (CANON) {
+        u64 rhi, rlo;
+        revcomp_key(hi, lo, k, rhi, rlo);
+        if (key_less(rhi, rlo, hi, lo)) { hi = rhi; lo = rlo; }
+    }
+    gtable_add<KW>(g, hi, lo, cnt);
+}
+
+// The probing insert (drain path): find-or-claim a slot for (hi, lo) starting at its home bucket and
+// add one; keys that find no slot within the probe budget, or arrive when the table is nearly full,
+// are counted in the global table.  Same wave-uniform loop shape as gtable_add (see there for why).
+// Returns true when the k-mer went to the global table.
+template <int KW, bool CANON>
+__device__ __forceinline__ bool lds_insert(StreamLds<KW>& L, const GTable& g, u64 hi, u64 lo, bool active, bool lds_ok, int k) {
     constexpr u32 M = StreamLds<KW>::LCAP - 1;
-    u32 h = kmc_hash32<KW>(hi, lo) & M;
+    u32 h = stream_home<KW>(hi, lo);
     int probes = lds_ok ? 0 : 1000;
-    bool done = false, to_global = false;
+    bool done = !active, to_global = false;
     u32 trips = 0;
     while (__builtin_amdgcn_ballot_w64(!done) != 0) {
         if (!done) {
-            if (probes >= 24 || ++trips > (1u << 20)) {
+            if (probes >= 16 || ++trips > (1u << 20)) {
                 to_global = true;
                 done = true;
             } else if (KW == 1) {
-                u64 cur = __hip_atomic_load(&L.lo[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                u64 cur = __hip_atomic_load(&L.slot[h].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur == KMC_EMPTY64) {
-                    cur = atomicCAS((unsigned long long*)&L.lo[h], KMC_EMPTY64, lo);
+                    cur = atomicCAS((unsigned long long*)&L.slot[h].lo, KMC_EMPTY64, lo);
                     if (cur == KMC_EMPTY64) { atomicAdd(&L.nfill, 1u); cur = lo; }
                 }
                 if (cur == lo) { atomicAdd(&L.cnt[h], 1u); done = true; }
                 else { h = (h + 1) & M; probes++; }
             } else {
-                u64 cur = __hip_atomic_load(&L.hi[h], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                u64* const phi = &reinterpret_cast<u64*>(&L.slot[h])[1];
+                u64* const plo = &reinterpret_cast<u64*>(&L.slot[h])[0];
+                u64 cur = __hip_atomic_load(phi, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (cur == KMC_EMPTY64) {
-                    u64 old = atomicCAS((unsigned long long*)&L.hi[h], KMC_EMPTY64, KMC_LOCKED64);
+                    u64 old = atomicCAS((unsigned long long*)phi, KMC_EMPTY64, KMC_LOCKED64);
                     if (old == KMC_EMPTY64) {
-                        __hip_atomic_store(&L.lo[h], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        __hip_atomic_store(&L.hi[h], hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(plo, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        __hip_atomic_store(phi, hi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         atomicAdd(&L.nfill, 1u);
                         atomicAdd(&L.cnt[h], 1u);
                         done = true;
                     }
                 } else if (cur == KMC_LOCKED64) {
                     // being published; examine it next trip
-                } else if (cur == hi && __hip_atomic_load(&L.lo[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == lo) {
+                } else if (cur == hi && __hip_atomic_load(plo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == lo) {
                     atomicAdd(&L.cnt[h], 1u);
                     done = true;
                 } else { h = (h + 1) & M; probes++; }
             }
         }
     }
-    if (to_global) gtable_add<KW>(g, hi, lo, 1);
-    return to_global;  // counted with a global atomic instead of the LDS partial table
+    if (to_global) stream_gadd<KW, CANON>(g, hi, lo, k, 1);
+    return to_global;
+}
+
+// empty the wave's miss buffer through the probing insert (all 64 lanes take part)
+template <int KW, bool CANON>
+__device__ __attribute__((noinline)) u32 stream_drain(StreamLds<KW>& L, const GTable& g, int wv, int lane, u32 nbuf, int k) {
+    u32 nglobal = 0;
+    const bool lds_ok = __hip_atomic_load(&L.nfill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (u32)(StreamLds<KW>::LCAP * 3 / 4);
+    for (u32 b = 0; b < nbuf; b += 64) {
+        const bool act = b + lane < nbuf;
+        u64 lo = 0, hi = 0;
+        if (act) {
+            lo = L.miss[wv][b + lane].lo;
+            if constexpr (KW == 2) hi = L.miss[wv][b + lane].hi;
+        }
+        nglobal += lds_insert<KW, CANON>(L, g, hi, lo, act, lds_ok, k) ? 1u : 0u;
+    }
+    return nglobal;
+}
+
+// hot path: one k-mer per lane.  Returns the new fill of the wave's miss buffer (wave-uniform).
+template <int KW>
+__device__ __forceinline__ u32 stream_count(StreamLds<KW>& L, int wv, u64 hi, u64 lo, bool ok, u32 nbuf) {
+    const u32 h = stream_home<KW>(hi, lo);
+    bool m0, m1;
+    if (KW == 1) {
+        const u64 k0 = __hip_atomic_load(&L.slot[h].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u64 k1 = __hip_atomic_load(&L.slot[h + 1].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        m0 = k0 == lo;
+        m1 = k1 == lo;
+    } else {
+        // (a slot being published shows LOCKED or EMPTY in its high word: a miss, settled by the drain;
+        // the low word is read after the high word it was published before)
+        const u64* s0 = reinterpret_cast<const u64*>(&L.slot[h]);
+        const u64 h0 = __hip_atomic_load(&s0[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u64 h1 = __hip_atomic_load(&s0[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u64 l0 = __hip_atomic_load(&s0[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const u64 l1 = __hip_atomic_load(&s0[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        m0 = h0 == hi && l0 == lo;
+        m1 = h1 == hi && l1 == lo;
+    }
+    const bool hit = ok && (m0 || m1);
+    if (hit) atomicAdd(&L.cnt[h + (m0 ? 0u : 1u)], 1u);
+    const bool miss = ok && !hit;
+    const u64 mb = __builtin_amdgcn_ballot_w64(miss);
+    if (mb != 0) {  // wave-uniform
+        if (miss) {
+            const u32 idx = nbuf + __builtin_amdgcn_mbcnt_hi((u32)(mb >> 32), __builtin_amdgcn_mbcnt_lo((u32)mb, 0u));
+            L.miss[wv][idx].lo = lo;
+            if constexpr (KW == 2) L.miss[wv][idx].hi = hi;
+        }
+        nbuf += (u32)__popcll(mb);
+    }
+    return nbuf;
 }
 
 // wide bit masks for the validity smear: 64 bits cover the 48-base window of KW==1,
@@ -138,12 +233,13 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
 
     if constexpr (SINK == 0) {
         for (int s = tid; s < StreamLds<KW>::LCAP; s += KMC_STREAM_THREADS) {
-            if (KW == 1) L.lo[s] = KMC_EMPTY64; else { L.hi[s] = KMC_EMPTY64; L.lo[s] = 0; }
+            if constexpr (KW == 1) L.slot[s].lo = KMC_EMPTY64; else { L.slot[s].hi = KMC_EMPTY64; L.slot[s].lo = 0; }
             L.cnt[s] = 0;
         }
         if (tid == 0) L.nfill = 0;
         __syncthreads();
     }
+    u32 nbuf = 0;  // fill of this wave's miss buffer (wave-uniform)
 
     const u64 gw = (u64)blockIdx.x * KMC_STREAM_WAVES + wv;
     // this launch covers chunks [chunk_begin, chunk_end) of the stream (windows ENDING there)
@@ -246,10 +342,11 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                     u64 nskip = range_begin - pp;
                     inv16 |= nskip >= 16 ? 0xFFFFu : ((1u << (u32)nskip) - 1u);
                 }
-                if (SINK == 1 || inv16 != 0xFFFFu) {
+                {  // (no per-lane skip of lanes without a valid window: the drain inside needs the whole wave)
                     // rc stream words from the LSB end: Yw[m] = rc word of lane-(NW-1-m)
+                    constexpr bool RC = CANON && SINK == 1;  // SINK == 0 counts forward keys; the flush picks the strand
                     u32 Yp[NW + 1];
-                    if (CANON) {
+                    if (RC) {
                         u32 Yw[2 * NW + 1];
 #pragma unroll
                         for (int m = 0; m < NW; ++m) Yw[m] = rc_word_be(X[NW - 1 - m]);
@@ -265,9 +362,6 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         }
                         Yp[NW] = 0;
                     }
-                    bool lds_ok = false;
-                    if constexpr (SINK == 0)
-                        lds_ok = __hip_atomic_load(&L.nfill, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (u32)(StreamLds<KW>::LCAP * 7 / 8);
                     u64* const o_lo = SINK == 1 ? out_lo + (pp - chunk_begin * KMC_CHUNK) : nullptr;
                     u64* const o_hi = (SINK == 1 && KW == 2) ? out_hi + (pp - chunk_begin * KMC_CHUNK) : nullptr;
 #pragma unroll
@@ -279,7 +373,7 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         u64 flo = ((u64)f[1] << 32 | f[0]) & mask_lo, fhi = 0;
                         if constexpr (KW == 2) fhi = ((u64)f[3] << 32 | f[2]) & mask_hi;
                         u64 klo = flo, khi = fhi;
-                        if (CANON) {
+                        if (RC) {
                             u32 r[2 * KW];
 #pragma unroll
                             for (int m = 0; m < 2 * KW; ++m) r[m] = alignbit(Yp[m + 1], Yp[m], 2 * j);
@@ -289,7 +383,12 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         }
                         const bool ok = !((inv16 >> j) & 1);
                         if constexpr (SINK == 0) {
-                            if (ok) { nglobal += lds_add<KW>(L, g, khi, klo, lds_ok) ? 1u : 0u; nk++; }
+                            nk += ok;
+                            nbuf = stream_count<KW>(L, wv, khi, klo, ok, nbuf);
+                            if (nbuf > KMC_STREAM_MISSBUF - 64) {  // wave-uniform: no room for another full step
+                                nglobal += stream_drain<KW, CANON>(L, g, wv, lane, nbuf, k);
+                                nbuf = 0;
+                            }
                         } else {
                             o_lo[j] = ok ? klo : ~0ull;
                             if (KW == 2) o_hi[j] = ok ? khi : ~0ull;
@@ -297,6 +396,9 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         }
                     }
                 }
+            }
+            if constexpr (SINK == 0) {
+                if (nbuf) { nglobal += stream_drain<KW, CANON>(L, g, wv, lane, nbuf, k); nbuf = 0; }
             }
             pw = wbe;
             pzb = zb;
@@ -310,8 +412,12 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
     if constexpr (SINK == 0) {
         __syncthreads();
         for (int s = tid; s < StreamLds<KW>::LCAP; s += KMC_STREAM_THREADS) {
-            u32 c = L.cnt[s];
-            if (c) gtable_add<KW>(g, KW == 2 ? L.hi[s] : 0ull, L.lo[s], c);
+            const u32 c = L.cnt[s];
+            if (c) {
+                u64 hi = 0;
+                if constexpr (KW == 2) hi = L.slot[s].hi;
+                stream_gadd<KW, CANON>(g, hi, L.slot[s].lo, k, c);
+            }
         }
     }
 }
