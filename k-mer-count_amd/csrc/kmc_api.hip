@@ -27,6 +27,7 @@
 #include "kmc_walk.cuh"
 #include "kmc_lr.cuh"
 #include "kmc_sort.cuh"
+#include "kmc_msd.cuh"
 #include "kmc_ingest.h"
 
 namespace {
@@ -75,6 +76,9 @@ struct kmc_ctx {
     bool walk_ws_clean = false;  // workspace header + dense counters are zero (left so by kmc_walk_unfold_kernel)
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
     DevBuf s_lo[2], s_hi[2], s_flags, s_pos, s_head;
+    // hand-written MSD radix sort (kmc_msd.cuh): per-range histograms, segment lists, terminals
+    DevBuf m_hist, m_stot, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_cnt, m_w[2];
+    MsdCtl* h_ctl = nullptr;  // pinned mirror of the sort's device counters
     struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0, cap = 0; };
     std::vector<Run> runs;       // live runs
     std::vector<Run> run_pool;   // buffers of dropped runs, reused (multi-GB hipMalloc/hipFree per batch is slow)
@@ -494,6 +498,125 @@ int sort_keys_buffers(kmc_ctx* c, u64 n, int* where) {
     return rc;
 }
 
+// ---- hand-written MSD radix sort + run-length (kmc_msd.cuh) ------------------------------------------
+// Sorts the n keys in lo[0] (hi[0] for two-word keys; w[0] = weights to sum, or null: every key counts
+// once), dropping all-ones filler keys, and appends the resulting sorted (key, count) run to c->runs.
+// lo[1] / hi[1] / w[1] are scratch of the same size.  One host synchronisation per level (the number
+// of segments that go on) and one for the size of the run.
+int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w[2], u64 n, unsigned kb) {
+    if (!n) return KMC_OK;
+    if (n >= (1ull << 32) - KMC_MSD_RANGE) return fail(c, KMC_ERR_ARG, "msd sort: more than 2^32 keys in one pass");
+    const int KW = c->KW;
+    const bool weights = w[0] != nullptr;
+    const u32 leaf_cap = KW == 1 ? KMC_MSD_LEAF1 : KMC_MSD_LEAF2;
+    const u64 max_seg = n / leaf_cap + 257;
+    const u64 max_ranges = n / KMC_MSD_RANGE + max_seg + 1;
+    const u64 term_cap = 16 * (n / leaf_cap) + 65536;
+    const u64 n_words = (n + 63) / 64;
+    int rc;
+#define MSD_ENSURE(buf, bytes) do { rc = ensure(c, (buf), (size_t)(bytes)); if (rc) return rc; } while (0)
+    MSD_ENSURE(c->m_hist, max_ranges * KMC_MSD_NB * sizeof(u32));
+    MSD_ENSURE(c->m_rmin, max_ranges * 2 * sizeof(u64));
+    MSD_ENSURE(c->m_rmax, max_ranges * 2 * sizeof(u64));
+    MSD_ENSURE(c->m_seg[0], max_seg * sizeof(MsdSeg));
+    MSD_ENSURE(c->m_seg[1], max_seg * sizeof(MsdSeg));
+    MSD_ENSURE(c->m_first, (max_seg + 1) * sizeof(u32));
+    MSD_ENSURE(c->m_cbase, max_seg * KMC_MSD_NB * sizeof(u32));
+    MSD_ENSURE(c->m_stot, max_seg * KMC_MSD_NB * sizeof(u32));
+    MSD_ENSURE(c->m_skip, max_seg * sizeof(u32));
+    MSD_ENSURE(c->m_term, term_cap * sizeof(MsdTerm));
+    MSD_ENSURE(c->m_ord, term_cap * sizeof(MsdTerm));
+    MSD_ENSURE(c->m_bitmap, n_words * sizeof(u64));
+    MSD_ENSURE(c->m_rank, n_words * sizeof(u32));
+    MSD_ENSURE(c->m_nd, term_cap * sizeof(u32));
+    MSD_ENSURE(c->m_base, term_cap * sizeof(u32));
+    MSD_ENSURE(c->m_ctl, sizeof(MsdCtl));
+    MSD_ENSURE(c->m_cnt, n * sizeof(u64));
+#undef MSD_ENSURE
+    if (!c->h_ctl) HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, sizeof(MsdCtl)));
+    MsdCtl* ctl = (MsdCtl*)c->m_ctl.p;
+    HIPCHK(c, hipMemsetAsync(ctl, 0, sizeof(MsdCtl), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->m_bitmap.p, 0, n_words * sizeof(u64), c->stream));
+    const MsdSeg root{0u, (u32)n};
+    HIPCHK(c, hipMemcpyAsync(c->m_seg[0].p, &root, sizeof(root), hipMemcpyHostToDevice, c->stream));
+    u32 n_seg = 1;
+    int cur = 0, par = 0;
+    const int levels = kb <= 8 ? 1 : (int)((kb + 7) / 8);
+    for (int l = 0; l < levels && n_seg; ++l) {
+        const int hi_bit = (int)kb - 8 * l;
+        const int width = hi_bit < 8 ? hi_bit : 8;
+        const int shift = hi_bit - width;
+        const u32 mask = (1u << width) - 1u;
+        const int last = shift == 0 ? 1 : 0;
+        MsdSeg* seg = (MsdSeg*)c->m_seg[cur].p;
+        MsdSeg* next = (MsdSeg*)c->m_seg[cur ^ 1].p;
+        u32* first = (u32*)c->m_first.p;
+        hipLaunchKernelGGL(kmc_msd_ranges_kernel, dim3(1), dim3(1024), 0, c->stream, (const MsdSeg*)seg, n_seg, first, ctl);
+        const u32 grid = (u32)std::min<u64>(n / KMC_MSD_RANGE + n_seg + 1, max_ranges);
+        const u64 *shi = hi[par], *slo = lo[par], *sw = weights ? w[par] : nullptr;
+        u64 *dhi = hi[par ^ 1], *dlo = lo[par ^ 1], *dw = weights ? w[par ^ 1] : nullptr;
+        if (KW == 1) hipLaunchKernelGGL(kmc_msd_hist_kernel<1>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, shi, slo, (const MsdSeg*)seg, n_seg, (const u32*)first, shift, mask, (int)kb, l == 0 ? 1 : 0,
+                                        (u32*)c->m_hist.p, (u64*)c->m_rmin.p, (u64*)c->m_rmax.p, (const MsdCtl*)ctl);
+        else hipLaunchKernelGGL(kmc_msd_hist_kernel<2>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, shi, slo, (const MsdSeg*)seg, n_seg, (const u32*)first, shift, mask, (int)kb, l == 0 ? 1 : 0,
+                                (u32*)c->m_hist.p, (u64*)c->m_rmin.p, (u64*)c->m_rmax.p, (const MsdCtl*)ctl);
+        HIPCHK(c, hipMemsetAsync(&ctl->n_next, 0, sizeof(u32), c->stream));
+        const u32 S = n_seg <= 4096 ? 65u : 1u;  // few segments = long ones: one digit column per wave
+        hipLaunchKernelGGL(kmc_msd_scan_a_kernel, dim3(n_seg * S), dim3(KMC_MSD_THREADS), 0, c->stream, n_seg, S, (const u32*)first, (u32*)c->m_hist.p, (u32*)c->m_stot.p);
+        hipLaunchKernelGGL(kmc_msd_scan_kernel, dim3(n_seg), dim3(KMC_MSD_THREADS), 0, c->stream, (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)c->m_stot.p,
+                           (const u64*)c->m_rmin.p, (const u64*)c->m_rmax.p, (u32*)c->m_cbase.p, (u32*)c->m_skip.p, last, l == 0 ? 1 : 0, leaf_cap, (u32)par,
+                           next, (u32)max_seg, (MsdTerm*)c->m_term.p, (u32)term_cap, (unsigned long long*)c->m_bitmap.p, ctl);
+#define MSD_SCATTER(KWV, WV)                                                                                                              \
+        hipLaunchKernelGGL((kmc_msd_scatter_kernel<KWV, WV>), dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, shi, slo, sw, dhi, dlo, dw, \
+                           (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)c->m_hist.p, (const u32*)c->m_cbase.p, (const u32*)c->m_skip.p, \
+                           shift, mask, (int)kb, l == 0 ? 1 : 0, (const MsdCtl*)ctl)
+        if (KW == 1) { if (weights) MSD_SCATTER(1, true); else MSD_SCATTER(1, false); }
+        else { if (weights) MSD_SCATTER(2, true); else MSD_SCATTER(2, false); }
+#undef MSD_SCATTER
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(MsdCtl), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->h_ctl->overflow) return fail(c, KMC_ERR_CAPACITY, "msd sort: segment / terminal list overflow (%u)", c->h_ctl->overflow);
+        n_seg = c->h_ctl->n_next;
+        cur ^= 1;
+        par ^= 1;
+    }
+    const u32 n_term = c->h_ctl->n_term;
+    if (!n_term) return KMC_OK;  // nothing but filler
+    // terminals in position order, their pairs, the dense run
+    hipLaunchKernelGGL(kmc_msd_bitrank_kernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long*)c->m_bitmap.p, (u32)n_words, (u32*)c->m_rank.p);
+    hipLaunchKernelGGL(kmc_msd_order_kernel, dim3(grid_for(c, n_term, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_term.p, n_term,
+                       (const unsigned long long*)c->m_bitmap.p, (const u32*)c->m_rank.p, (MsdTerm*)c->m_ord.p);
+    u64* t_cnt0 = (u64*)c->m_cnt.p;  // pair staging: counts (keys are staged in the key buffers themselves)
+#define MSD_LEAF(KWV, WV)                                                                                                                   \
+    do {                                                                                                                                    \
+        static bool attr = false;                                                                                                           \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_msd_leaf_kernel<KWV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdLeafLds<KWV, WV>)); attr = true; } \
+        hipLaunchKernelGGL((kmc_msd_leaf_kernel<KWV, WV>), dim3(n_term), dim3(KMC_MSD_THREADS), sizeof(MsdLeafLds<KWV, WV>), c->stream,           \
+                           (const u64*)hi[0], (const u64*)lo[0], (const u64*)(weights ? w[0] : nullptr), (const u64*)hi[1], (const u64*)lo[1], (const u64*)(weights ? w[1] : nullptr), \
+                           (const MsdTerm*)c->m_ord.p, n_term, (int)kb, hi[0], lo[0], hi[1], lo[1], t_cnt0, (u32*)c->m_nd.p); \
+    } while (0)
+    if (KW == 1) { if (weights) MSD_LEAF(1, true); else MSD_LEAF(1, false); }
+    else { if (weights) MSD_LEAF(2, true); else MSD_LEAF(2, false); }
+#undef MSD_LEAF
+    hipLaunchKernelGGL(kmc_msd_scan_nd_kernel, dim3(1), dim3(1024), 0, c->stream, (const u32*)c->m_nd.p, n_term, (u32*)c->m_base.p, ctl);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(MsdCtl), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const u64 n_pairs = c->h_ctl->n_pairs;
+    kmc_ctx::Run run;
+    rc = take_run(c, std::max<u64>(n_pairs, 1), &run);
+    if (rc) return rc;
+    run.n = n_pairs;
+    c->runs.push_back(run);
+    if (KW == 1) hipLaunchKernelGGL(kmc_msd_gather_kernel<1>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, (const u32*)c->m_nd.p, (const u32*)c->m_base.p,
+                                    (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1], (const u64*)t_cnt0, run.hi, run.lo, run.cnt);
+    else hipLaunchKernelGGL(kmc_msd_gather_kernel<2>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, (const u32*)c->m_nd.p, (const u32*)c->m_base.p,
+                            (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1], (const u64*)t_cnt0, run.hi, run.lo, run.cnt);
+    HIPCHK(c, hipGetLastError());
+    if (!n_pairs) { c->run_pool.push_back(c->runs.back()); c->runs.pop_back(); }
+    return KMC_OK;
+}
+
 // Count the windows ending in [range_begin, n_bases) by extract -> sort -> run-length, in sub-batches
 // of at most 2^31 base positions (2 x 16-32 GiB of keys in flight).  Each sub-batch leaves one run.
 int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 range_begin) {
@@ -509,10 +632,10 @@ int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
         }
         int rc = launch_extract(c, d_bases, d_offsets, n_reads, n_bases, cb, ce, range_begin, (u64*)c->s_hi[0].p, (u64*)c->s_lo[0].p);
         if (rc) return rc;
-        int w = 0;
-        rc = sort_keys_buffers(c, n, &w);
-        if (rc) return rc;
-        rc = collapse_runs(c, c->KW == 2 ? (const u64*)c->s_hi[w].p : nullptr, (const u64*)c->s_lo[w].p, nullptr, n, true);
+        u64* const khi[2] = {(u64*)c->s_hi[0].p, (u64*)c->s_hi[1].p};
+        u64* const klo[2] = {(u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p};
+        u64* const kwt[2] = {nullptr, nullptr};
+        rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen);
         if (rc) return rc;
     }
     c->pending = true;
@@ -824,7 +947,10 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     if (c->spill_cnt) (void)hipFree(c->spill_cnt);
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
                       &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo, &c->vr_reads, &c->vr_cnt, &c->vr_pos,
-                      &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->s_flags, &c->s_pos, &c->s_head};
+                      &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->s_flags, &c->s_pos, &c->s_head,
+                      &c->m_hist, &c->m_stot, &c->m_rmin, &c->m_rmax, &c->m_seg[0], &c->m_seg[1], &c->m_first, &c->m_cbase, &c->m_skip, &c->m_term, &c->m_ord,
+                      &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_cnt, &c->m_w[0], &c->m_w[1]};
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     try { free_runs(c, true); } catch (...) { /* (only the pool bookkeeping can throw; the buffers it could not list leak with the process) */ }
     for (DevBuf* b : bufs) free_buf(*b);
     for (hipEvent_t e : c->lev) (void)hipEventDestroy(e);

@@ -1,0 +1,618 @@
+// kmc_msd.cuh -- hand-written MSD radix sort + run-length for packed k-mer keys: the GPU form of the
+// reference's grouping step, bucket_sort / radix_sort / sort() + "count the repeated lines"
+// (k-mer-count/src/main.rs:9-40,84,87), for inputs where almost every key is new (KMC_ALGO_SORT, the
+// reference's own LR mode) and for ordering large count tables.
+//
+// The reference sorts 54-character strings one character position at a time from the END
+// (main.rs:34-40: 53 stable bucket passes over everything).  Here keys are 2 bits per base, MSB
+// first, so unsigned order = string order, and the sort goes from the FRONT, eight bits (four bases)
+// per pass, so that a key crosses HBM a few times instead of once per digit:
+//
+//   level l   every ACTIVE segment (a span of the key array whose keys share their first 8*l bits) is
+//             partitioned by its next 8 bits: kmc_msd_hist_kernel counts per range of 16 Ki keys,
+//             kmc_msd_scan_kernel turns the counts into destinations and classifies the 256 children,
+//             kmc_msd_scatter_kernel moves the keys into the other buffer.  Children of at most
+//             KMC_MSD_LEAF keys, children whose keys are all equal and children with no bits left are
+//             TERMINAL; the rest are the next level's active segments.  Positions are shared by both
+//             buffers, so position order is key order at every level.
+//   leaves    one workgroup per terminal segment: an LDS pass on the next 8 bits, then every
+//             sub-bucket is rank-sorted inside a wave (all-pairs compare through v_readlane, no data
+//             movement), then run-length: (key, count) pairs.
+//   output    the terminals are ordered by position with a bitmap + popcount scan, their pair counts
+//             are scanned, and the pairs are gathered into one dense sorted run.
+//
+// Invalid positions (all-ones filler from the extraction kernel) fall into a 257th bucket at level 0
+// and are dropped.  Keys may carry a 64-bit weight (an existing count): the run-length then sums
+// weights -- that is how count tables and earlier runs are merged and ordered.
+#pragma once
+#include "kmc_device.cuh"
+
+#define KMC_MSD_RANGE 16384   // keys per histogram / scatter workgroup
+#define KMC_MSD_NB 257        // digit bins: 256 + "invalid position"
+#define KMC_MSD_THREADS 256
+#define KMC_MSD_LEAF1 4096    // leaf capacity, one-word keys  (two LDS images of 32 KB)
+#define KMC_MSD_LEAF2 2048    // leaf capacity, two-word keys
+
+struct MsdSeg { u32 begin, len; };
+// kind 0: leaf (sort in LDS); kind 1: all keys equal (one pair, key = first element)
+struct MsdTerm { u32 begin, len, kind, parity; };
+
+// device-side bookkeeping of one sort (all counters of a level are zeroed by the host before use)
+struct MsdCtl {
+    u32 n_next;      // active segments appended for the next level
+    u32 n_term;      // terminals so far
+    u32 n_valid;     // keys that are not filler (written at level 0)
+    u32 n_ranges;    // ranges of the current level (written by kmc_msd_ranges_kernel)
+    u32 overflow;    // a list ran out of room (host checks)
+    u32 n_pairs;     // total (key, count) pairs (written by the terminal scan)
+    u32 pad[2];
+};
+
+template <int KW>
+__device__ __forceinline__ bool msd_is_filler(u64 hi, u64 lo, int kb) {
+    if (KW == 1) return kb < 64 && (lo >> kb) != 0;
+    return (hi >> (kb - 64)) != 0;  // kb in [64, 126]
+}
+// bits [shift, shift + 8) of the key (the caller masks the last, narrower level)
+template <int KW>
+__device__ __forceinline__ u32 msd_bits(u64 hi, u64 lo, int shift) {
+    if (KW == 1) return (u32)(lo >> shift);
+    if (shift >= 64) return (u32)(hi >> (shift - 64));
+    if (shift == 0) return (u32)lo;
+    return (u32)((lo >> shift) | (hi << (64 - shift)));
+}
+
+// first[i] = number of ranges of segments 0..i-1; ctl->n_ranges = total.  One workgroup.
+__global__ __launch_bounds__(1024)
+void kmc_msd_ranges_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, u32* __restrict__ first, MsdCtl* ctl) {
+    __shared__ u32 part[1024];
+    const u32 tid = threadIdx.x;
+    const u32 per = (n_seg + 1023) / 1024;
+    const u32 a = tid * per, b = min(a + per, n_seg);
+    u32 s = 0;
+    for (u32 i = a; i < b; ++i) s += (seg[i].len + KMC_MSD_RANGE - 1) / KMC_MSD_RANGE;
+    part[tid] = s;
+    __syncthreads();
+    for (u32 o = 1; o < 1024; o <<= 1) {
+        u32 v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = tid ? part[tid - 1] : 0;
+    for (u32 i = a; i < b; ++i) { first[i] = run; run += (seg[i].len + KMC_MSD_RANGE - 1) / KMC_MSD_RANGE; }
+    if (tid == 1023) { first[n_seg] = part[1023]; ctl->n_ranges = part[1023]; }
+}
+
+// segment of range r: last s with first[s] <= r
+__device__ __forceinline__ u32 msd_seg_of(const u32* __restrict__ first, u32 n_seg, u32 r) {
+    u32 lo = 0, hi = n_seg;
+    while (hi - lo > 1) {
+        const u32 mid = (lo + hi) >> 1;
+        if (first[mid] <= r) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// per range: digit histogram (hist[r][257]) and min / max key (all-equal segments end here)
+template <int KW>
+__global__ __launch_bounds__(KMC_MSD_THREADS)
+void kmc_msd_hist_kernel(const u64* __restrict__ khi, const u64* __restrict__ klo, const MsdSeg* __restrict__ seg, u32 n_seg,
+                         const u32* __restrict__ first, int shift, u32 mask, int kb, int level0,
+                         u32* __restrict__ hist, u64* __restrict__ rmin, u64* __restrict__ rmax, const MsdCtl* __restrict__ ctl) {
+    __shared__ u32 h[4][KMC_MSD_NB + 3];
+    __shared__ u64 smin[4][2], smax[4][2];
+    const u32 r = blockIdx.x, tid = threadIdx.x, wv = tid >> 6;
+    if (r >= ctl->n_ranges) return;  // (the grid is the host's upper bound)
+    for (u32 i = tid; i < 4 * (KMC_MSD_NB + 3); i += KMC_MSD_THREADS) (&h[0][0])[i] = 0;
+    __syncthreads();
+    const u32 s = msd_seg_of(first, n_seg, r);
+    const u32 idx = r - first[s];
+    const u32 b = seg[s].begin + idx * KMC_MSD_RANGE;
+    const u32 n = min((u32)KMC_MSD_RANGE, seg[s].len - idx * KMC_MSD_RANGE);
+    u64 mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
+    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
+        const u64 lo = klo[b + i], hi = KW == 2 ? khi[b + i] : 0ull;
+        u32 d;
+        if (level0 && msd_is_filler<KW>(hi, lo, kb)) d = 256;
+        else {
+            d = msd_bits<KW>(hi, lo, shift) & mask;
+            if (key_less(hi, lo, mnh, mnl)) { mnh = hi; mnl = lo; }
+            if (key_less(mxh, mxl, hi, lo)) { mxh = hi; mxl = lo; }
+        }
+        atomicAdd(&h[wv][d], 1u);
+    }
+    // wave min / max
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 oh = __shfl_xor(mnh, o), ol = __shfl_xor(mnl, o);
+        if (key_less(oh, ol, mnh, mnl)) { mnh = oh; mnl = ol; }
+        const u64 ph = __shfl_xor(mxh, o), pl = __shfl_xor(mxl, o);
+        if (key_less(mxh, mxl, ph, pl)) { mxh = ph; mxl = pl; }
+    }
+    if ((tid & 63) == 0) { smin[wv][0] = mnh; smin[wv][1] = mnl; smax[wv][0] = mxh; smax[wv][1] = mxl; }
+    __syncthreads();
+    for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_THREADS) hist[(size_t)r * KMC_MSD_NB + d] = h[0][d] + h[1][d] + h[2][d] + h[3][d];
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w) {
+            if (key_less(smin[w][0], smin[w][1], mnh, mnl)) { mnh = smin[w][0]; mnl = smin[w][1]; }
+            if (key_less(mxh, mxl, smax[w][0], smax[w][1])) { mxh = smax[w][0]; mxl = smax[w][1]; }
+        }
+        rmin[2 * (size_t)r] = mnh; rmin[2 * (size_t)r + 1] = mnl;
+        rmax[2 * (size_t)r] = mxh; rmax[2 * (size_t)r + 1] = mxl;
+    }
+}
+
+// Scan, part A: for every (segment, digit) the exclusive running offsets over the segment's ranges (in
+// place in hist) and the digit's total (stot[s][257]).  One WAVE scans one digit's column 64 ranges at a
+// time; the grid is n_seg x S workgroups of four waves, wave w of workgroup j of a segment takes the
+// digits j*4 + w + 4*S*i.  (S = 65: one digit per wave -- level 0 is ONE segment of tens of thousands
+// of ranges, which a single workgroup would walk for milliseconds; S = 1 when there are many segments.)
+__global__ __launch_bounds__(KMC_MSD_THREADS)
+void kmc_msd_scan_a_kernel(u32 n_seg, u32 S, const u32* __restrict__ first, u32* __restrict__ hist, u32* __restrict__ stot) {
+    const u32 s = blockIdx.x / S, j = blockIdx.x % S, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (s >= n_seg) return;
+    const u32 r0 = first[s], r1 = first[s + 1];
+    for (u32 d = j * 4 + wv; d < KMC_MSD_NB; d += 4 * S) {
+        u32 run = 0;
+        for (u32 base = r0; base < r1; base += 64) {
+            const u32 r = base + lane;
+            const size_t i = (size_t)r * KMC_MSD_NB + d;
+            const u32 v = r < r1 ? hist[i] : 0u;
+            u32 inc = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(inc, o); if ((int)lane >= o) inc += t; }
+            if (r < r1) hist[i] = run + inc - v;
+            run += __shfl(inc, 63);
+        }
+        if (lane == 0) stot[(size_t)s * KMC_MSD_NB + d] = run;
+    }
+}
+
+// Scan, part B: one workgroup per active segment: child destinations (cbase[s][257]) from the digit
+// totals, and the classification of the children.
+//   seg_skip[s] = 1: every key of the segment is equal -- it becomes a terminal as it stands (in the
+//   SOURCE buffer) and its ranges are not scattered.
+__global__ __launch_bounds__(KMC_MSD_THREADS)
+void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* __restrict__ first, const u32* __restrict__ stot,
+                         const u64* __restrict__ rmin, const u64* __restrict__ rmax, u32* __restrict__ cbase, u32* __restrict__ seg_skip,
+                         int last_level, int level0, u32 leaf_cap, u32 src_parity,
+                         MsdSeg* __restrict__ next, u32 next_cap, MsdTerm* __restrict__ term, u32 term_cap,
+                         unsigned long long* __restrict__ bitmap, MsdCtl* ctl) {
+    __shared__ u32 tot[KMC_MSD_NB + 7];
+    __shared__ u32 wsum[4];
+    __shared__ u64 smm[4][4];
+    const u32 s = blockIdx.x, tid = threadIdx.x;
+    const u32 r0 = first[s], r1 = first[s + 1];
+    // are all keys of the segment equal?  (fold the ranges' min / max)
+    {
+        u64 mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
+        for (u32 r = r0 + tid; r < r1; r += KMC_MSD_THREADS) {
+            const u64 ah = rmin[2 * (size_t)r], al = rmin[2 * (size_t)r + 1], bh = rmax[2 * (size_t)r], bl = rmax[2 * (size_t)r + 1];
+            if (key_less(ah, al, mnh, mnl)) { mnh = ah; mnl = al; }
+            if (key_less(mxh, mxl, bh, bl)) { mxh = bh; mxl = bl; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const u64 oh = __shfl_xor(mnh, o), ol = __shfl_xor(mnl, o);
+            if (key_less(oh, ol, mnh, mnl)) { mnh = oh; mnl = ol; }
+            const u64 ph = __shfl_xor(mxh, o), pl = __shfl_xor(mxl, o);
+            if (key_less(mxh, mxl, ph, pl)) { mxh = ph; mxl = pl; }
+        }
+        if ((tid & 63) == 0) { smm[tid >> 6][0] = mnh; smm[tid >> 6][1] = mnl; smm[tid >> 6][2] = mxh; smm[tid >> 6][3] = mxl; }
+    }
+    for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_THREADS) tot[d] = stot[(size_t)s * KMC_MSD_NB + d];
+    __syncthreads();
+    bool all_equal;
+    {
+        u64 mnh = smm[0][0], mnl = smm[0][1], mxh = smm[0][2], mxl = smm[0][3];
+        for (int w = 1; w < 4; ++w) {
+            if (key_less(smm[w][0], smm[w][1], mnh, mnl)) { mnh = smm[w][0]; mnl = smm[w][1]; }
+            if (key_less(mxh, mxl, smm[w][2], smm[w][3])) { mxh = smm[w][2]; mxl = smm[w][3]; }
+        }
+        all_equal = mnh == mxh && mnl == mxl;
+    }
+    const u32 n_filler = level0 ? tot[256] : 0;
+    const bool equal = all_equal && seg[s].len > n_filler && (!level0 || n_filler == 0);
+    // exclusive scan of tot[0..255] -> child begin (the filler bucket is dropped)
+    const u32 mine = tot[tid];
+    u32 inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if ((int)(tid & 63) >= o) inc += v; }
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    u32 wbase = 0;
+    for (u32 w = 0; w < (tid >> 6); ++w) wbase += wsum[w];
+    const u32 cb = seg[s].begin + wbase + inc - mine;
+    cbase[(size_t)s * KMC_MSD_NB + tid] = cb;
+    __shared__ u32 cb_s[256];
+    cb_s[tid] = cb;
+    __syncthreads();
+    if (tid != 0) return;
+    cbase[(size_t)s * KMC_MSD_NB + 256] = 0;
+    seg_skip[s] = equal ? 1u : 0u;
+    if (level0) ctl->n_valid = seg[s].len - n_filler;
+    auto emit_term = [&](u32 b, u32 l, u32 kind, u32 parity) {
+        const u32 i = atomicAdd(&ctl->n_term, 1u);
+        if (i < term_cap) {
+            term[i] = MsdTerm{b, l, kind, parity};
+            atomicOr(&bitmap[b >> 6], 1ull << (b & 63));
+        } else atomicOr(&ctl->overflow, 1u);
+    };
+    if (equal) {  // stays where it is (source buffer): one pair
+        emit_term(seg[s].begin, seg[s].len, 1u, src_parity);
+        return;
+    }
+    // children, in position order: large ones go on to the next level (or, with no bits left, are one
+    // pair each); runs of consecutive small ones are merged into leaves of at most leaf_cap keys (a
+    // leaf sorts whatever keys it holds, so it need not be a single child)
+    u32 gb = 0, gl = 0;
+    for (u32 d = 0; d < 256; ++d) {
+        const u32 m = tot[d];
+        if (!m) continue;
+        if (m > leaf_cap) {
+            if (gl) { emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u); gl = 0; }
+            if (last_level) emit_term(cb_s[d], m, 1u, src_parity ^ 1u);
+            else {
+                const u32 i = atomicAdd(&ctl->n_next, 1u);
+                if (i < next_cap) next[i] = MsdSeg{cb_s[d], m}; else atomicOr(&ctl->overflow, 2u);
+            }
+        } else {
+            if (gl && gl + m > leaf_cap) { emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u); gl = 0; }
+            if (!gl) gb = cb_s[d];
+            gl += m;
+        }
+    }
+    if (gl) emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u);
+}
+
+// per range: move every key (and weight) to its child's span in the other buffer
+template <int KW, bool WEIGHTS>
+__global__ __launch_bounds__(KMC_MSD_THREADS)
+void kmc_msd_scatter_kernel(const u64* __restrict__ khi, const u64* __restrict__ klo, const u64* __restrict__ kw,
+                            u64* __restrict__ ohi, u64* __restrict__ olo, u64* __restrict__ ow,
+                            const MsdSeg* __restrict__ seg, u32 n_seg, const u32* __restrict__ first,
+                            const u32* __restrict__ hist, const u32* __restrict__ cbase, const u32* __restrict__ seg_skip,
+                            int shift, u32 mask, int kb, int level0, const MsdCtl* __restrict__ ctl) {
+    __shared__ u32 cur[KMC_MSD_NB + 3];
+    const u32 r = blockIdx.x, tid = threadIdx.x;
+    if (r >= ctl->n_ranges) return;
+    const u32 s = msd_seg_of(first, n_seg, r);
+    if (seg_skip[s]) return;  // (block-uniform)
+    for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_THREADS) cur[d] = cbase[(size_t)s * KMC_MSD_NB + d] + hist[(size_t)r * KMC_MSD_NB + d];
+    __syncthreads();
+    const u32 idx = r - first[s];
+    const u32 b = seg[s].begin + idx * KMC_MSD_RANGE;
+    const u32 n = min((u32)KMC_MSD_RANGE, seg[s].len - idx * KMC_MSD_RANGE);
+    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
+        const u64 lo = klo[b + i], hi = KW == 2 ? khi[b + i] : 0ull;
+        if (level0 && msd_is_filler<KW>(hi, lo, kb)) continue;
+        const u32 d = msd_bits<KW>(hi, lo, shift) & mask;
+        const u32 p = atomicAdd(&cur[d], 1u);
+        olo[p] = lo;
+        if (KW == 2) ohi[p] = hi;
+        if (WEIGHTS) ow[p] = kw[b + i];
+    }
+}
+
+// ---- terminals in position order ---------------------------------------------------------------
+// rank[w] = number of set bits in bitmap words 0..w-1 (one workgroup; the bitmap has one bit per key)
+__global__ __launch_bounds__(1024)
+void kmc_msd_bitrank_kernel(const unsigned long long* __restrict__ bitmap, u32 n_words, u32* __restrict__ rank) {
+    __shared__ u32 part[1024];
+    const u32 tid = threadIdx.x;
+    const u32 per = (n_words + 1023) / 1024;
+    const u32 a = tid * per, b = min(a + per, n_words);
+    u32 s = 0;
+    for (u32 i = a; i < b; ++i) s += (u32)__popcll(bitmap[i]);
+    part[tid] = s;
+    __syncthreads();
+    for (u32 o = 1; o < 1024; o <<= 1) {
+        u32 v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = tid ? part[tid - 1] : 0;
+    for (u32 i = a; i < b; ++i) { rank[i] = run; run += (u32)__popcll(bitmap[i]); }
+}
+// ordered[t] = the terminal whose begin has ordinal t
+__global__ void kmc_msd_order_kernel(const MsdTerm* __restrict__ term, u32 n_term, const unsigned long long* __restrict__ bitmap,
+                                     const u32* __restrict__ rank, MsdTerm* __restrict__ ordered) {
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_term; i += gridDim.x * blockDim.x) {
+        const u32 p = term[i].begin;
+        const unsigned long long below = bitmap[p >> 6] & ((1ull << (p & 63)) - 1ull);
+        ordered[rank[p >> 6] + (u32)__popcll(below)] = term[i];
+    }
+}
+// exclusive scan of nd[0..n) -> base[0..n), total -> ctl->n_pairs (one workgroup)
+__global__ __launch_bounds__(1024)
+void kmc_msd_scan_nd_kernel(const u32* __restrict__ nd, u32 n, u32* __restrict__ base, MsdCtl* ctl) {
+    __shared__ u32 part[1024];
+    const u32 tid = threadIdx.x;
+    const u32 per = (n + 1023) / 1024;
+    const u32 a = tid * per, b = min(a + per, n);
+    u32 s = 0;
+    for (u32 i = a; i < b; ++i) s += nd[i];
+    part[tid] = s;
+    __syncthreads();
+    for (u32 o = 1; o < 1024; o <<= 1) {
+        u32 v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = tid ? part[tid - 1] : 0;
+    for (u32 i = a; i < b; ++i) { base[i] = run; run += nd[i]; }
+    if (tid == 1023) ctl->n_pairs = part[1023];
+}
+
+// ---- leaves ------------------------------------------------------------------------------------
+// One workgroup per terminal (in position order).  Result: the terminal's (key, count) pairs, sorted,
+// written IN PLACE at the terminal's span of the pair staging arrays (t_hi/t_lo/t_cnt; at most len
+// pairs), and nd[t] = their number.  kmc_msd_gather_kernel then makes the run dense.
+template <int KW, bool WEIGHTS> struct MsdLeafLds {
+    static constexpr int CAP = KW == 1 ? KMC_MSD_LEAF1 : KMC_MSD_LEAF2;
+    u64 a_lo[CAP], b_lo[CAP];
+    u64 a_hi[KW == 2 ? CAP : 1], b_hi[KW == 2 ? CAP : 1];
+    u64 a_w[WEIGHTS ? CAP : 1], b_w[CAP];   // weights (counts) of the keys; b_w also receives the run sums
+    u32 cnt[256], off[257];
+    u32 wsum[4];
+    u32 bad;                  // a sub-bucket was too large for the in-wave rank sort
+    u32 n_out;
+};
+
+// in-wave rank sort of m <= 64 keys held one per lane (lanes >= m idle): returns the sorted position
+// of this lane's key; equal keys keep their lane order
+template <int KW>
+__device__ __forceinline__ u32 msd_wave_rank(u64 hi, u64 lo, u32 m, u32 lane) {
+    u32 rank = 0;
+    for (u32 j = 0; j < m; ++j) {
+        const u64 ol = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(lo >> 32), (int)j) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)lo, (int)j);
+        u64 oh = 0;
+        if (KW == 2) oh = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(hi >> 32), (int)j) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)hi, (int)j);
+        const bool less = key_less(oh, ol, hi, lo);
+        const bool eq = oh == hi && ol == lo;
+        rank += (less || (eq && j < lane)) ? 1u : 0u;
+    }
+    return rank;
+}
+
+template <int KW, bool WEIGHTS>
+__global__ __launch_bounds__(KMC_MSD_THREADS)
+void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo0, const u64* __restrict__ w0,
+                         const u64* __restrict__ hi1, const u64* __restrict__ lo1, const u64* __restrict__ w1,
+                         const MsdTerm* __restrict__ term, u32 n_term, int kb,
+                         u64* __restrict__ s_hi0, u64* __restrict__ s_lo0, u64* __restrict__ s_hi1, u64* __restrict__ s_lo1,
+                         u64* __restrict__ t_cnt, u32* __restrict__ nd) {
+    extern __shared__ __align__(16) unsigned char msd_smem[];
+    MsdLeafLds<KW, WEIGHTS>& L = *reinterpret_cast<MsdLeafLds<KW, WEIGHTS>*>(msd_smem);
+    constexpr int CAP = MsdLeafLds<KW, WEIGHTS>::CAP;
+    const u32 t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const MsdTerm T = term[t];
+    const u64* khi = T.parity ? hi1 : hi0;
+    const u64* klo = T.parity ? lo1 : lo0;
+    const u64* kw = T.parity ? w1 : w0;
+    // pair staging: the OTHER buffer at the terminal's own positions (dead there: an ancestor's keys)
+    u64* const t_lo = T.parity ? s_lo0 : s_lo1;
+    u64* const t_hi = T.parity ? s_hi0 : s_hi1;
+    if (T.kind == 1) {  // all keys equal: one pair
+        if (!WEIGHTS) {
+            if (tid == 0) { t_lo[T.begin] = klo[T.begin]; if (KW == 2) t_hi[T.begin] = khi[T.begin]; t_cnt[T.begin] = T.len; nd[t] = 1; }
+        } else {
+            u64 s = 0;
+            for (u32 i = tid; i < T.len; i += KMC_MSD_THREADS) s += kw[T.begin + i];
+            s = wave_sum_u64(s);
+            __shared__ u64 ws[4];
+            if (lane == 0) ws[wv] = s;
+            __syncthreads();
+            if (tid == 0) { t_lo[T.begin] = klo[T.begin]; if (KW == 2) t_hi[T.begin] = khi[T.begin]; t_cnt[T.begin] = ws[0] + ws[1] + ws[2] + ws[3]; nd[t] = 1; }
+        }
+        return;
+    }
+    const u32 n = T.len;  // <= CAP
+    // 1. load; the sub-bucket digit = the 8 bits below the prefix the keys of a leaf may still differ
+    //    in.  That prefix is not recorded, so take the highest bit in which any two keys differ.
+    u64 xh = 0, xl = 0;
+    u64 fh = 0, fl = 0;
+    if (n) { fl = klo[T.begin]; if (KW == 2) fh = khi[T.begin]; }
+    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
+        const u64 lo = klo[T.begin + i], hi = KW == 2 ? khi[T.begin + i] : 0ull;
+        L.a_lo[i] = lo;
+        if (KW == 2) L.a_hi[i] = hi;
+        if (WEIGHTS) L.a_w[i] = kw[T.begin + i];
+        xl |= lo ^ fl;
+        xh |= hi ^ fh;
+    }
+    if (tid < 256) L.cnt[tid] = 0;
+    if (tid == 0) { L.bad = 0; L.n_out = 0; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { xl |= __shfl_xor(xl, o); xh |= __shfl_xor(xh, o); }
+    __shared__ u64 sx[4][2];
+    if (lane == 0) { sx[wv][0] = xh; sx[wv][1] = xl; }
+    __syncthreads();
+    xh = sx[0][0] | sx[1][0] | sx[2][0] | sx[3][0];
+    xl = sx[0][1] | sx[1][1] | sx[2][1] | sx[3][1];
+    int top = -1;  // highest differing bit
+    if (KW == 2 && xh) top = 127 - __clzll((long long)xh);
+    else if (xl) top = 63 - __clzll((long long)xl);
+    if (top < 0) {  // every key of the leaf is the same: one pair
+        u64 sw = 0;
+        if (WEIGHTS) {
+            for (u32 i = tid; i < n; i += KMC_MSD_THREADS) sw += L.a_w[i];
+            sw = wave_sum_u64(sw);
+            if (lane == 0) sx[wv][0] = sw;
+            __syncthreads();
+            sw = sx[0][0] + sx[1][0] + sx[2][0] + sx[3][0];
+        } else sw = n;
+        if (tid == 0) { t_lo[T.begin] = fl; if (KW == 2) t_hi[T.begin] = fh; t_cnt[T.begin] = sw; nd[t] = n ? 1u : 0u; }
+        return;
+    }
+    int shift = top - 7;
+    if (shift < 0) shift = 0;
+    // 2. LDS pass: a -> b grouped by digit
+    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) atomicAdd(&L.cnt[msd_bits<KW>(KW == 2 ? L.a_hi[i] : 0ull, L.a_lo[i], shift) & 255u], 1u);
+    __syncthreads();
+    {
+        const u32 mine = L.cnt[tid];
+        u32 inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+        if (lane == 63) L.wsum[wv] = inc;
+        __syncthreads();
+        u32 wbase = 0;
+        for (u32 w = 0; w < wv; ++w) wbase += L.wsum[w];
+        L.off[tid] = wbase + inc - mine;
+        if (tid == 255) L.off[256] = wbase + inc;
+        __syncthreads();
+        L.cnt[tid] = L.off[tid];  // cursors
+        __syncthreads();
+    }
+    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
+        const u64 lo = L.a_lo[i], hi = KW == 2 ? L.a_hi[i] : 0ull;
+        const u32 p = atomicAdd(&L.cnt[msd_bits<KW>(hi, lo, shift) & 255u], 1u);
+        L.b_lo[p] = lo;
+        if (KW == 2) L.b_hi[p] = hi;
+        if (WEIGHTS) L.b_w[p] = L.a_w[i];
+    }
+    __syncthreads();
+    // 3. every sub-bucket: rank sort inside a wave, b -> a (sub-buckets of more than 64 keys in
+    //    rounds: the keys of the bucket that are smaller are counted 64 at a time)
+    for (u32 d = wv; d < 256; d += 4) {
+        const u32 o = L.off[d], m = L.off[d + 1] - o;
+        if (m == 0) continue;
+        if (m <= 64) {
+            u64 lo = 0, hi = 0, w = 0;
+            if (lane < m) { lo = L.b_lo[o + lane]; if (KW == 2) hi = L.b_hi[o + lane]; if (WEIGHTS) w = L.b_w[o + lane]; }
+            const u32 rk = msd_wave_rank<KW>(hi, lo, m, lane);
+            if (lane < m) { L.a_lo[o + rk] = lo; if (KW == 2) L.a_hi[o + rk] = hi; if (WEIGHTS) L.a_w[o + rk] = w; }
+        } else if (m <= 1024) {
+            // all-pairs in rounds: my key(s) against every block of 64 keys of the bucket
+            for (u32 c = 0; c < m; c += 64) {          // the chunk whose keys get their positions
+                const u32 i = c + lane;
+                u64 lo = 0, hi = 0, w = 0;
+                const bool have = i < m;
+                if (have) { lo = L.b_lo[o + i]; if (KW == 2) hi = L.b_hi[o + i]; if (WEIGHTS) w = L.b_w[o + i]; }
+                u32 rk = 0;
+                for (u32 e = 0; e < m; e += 64) {      // against chunk e
+                    const u32 j = e + lane;
+                    u64 ql = ~0ull, qh = ~0ull;
+                    if (j < m) { ql = L.b_lo[o + j]; qh = KW == 2 ? L.b_hi[o + j] : 0ull; }
+                    const u32 mm = min(64u, m - e);
+                    for (u32 x = 0; x < mm; ++x) {
+                        const u64 ol = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(ql >> 32), (int)x) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)ql, (int)x);
+                        u64 oh = 0;
+                        if (KW == 2) oh = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(qh >> 32), (int)x) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)qh, (int)x);
+                        const bool less = key_less(oh, ol, hi, lo);
+                        const bool eq = oh == hi && ol == lo;
+                        rk += (less || (eq && (e + x) < i)) ? 1u : 0u;
+                    }
+                }
+                if (have) { L.a_lo[o + rk] = lo; if (KW == 2) L.a_hi[o + rk] = hi; if (WEIGHTS) L.a_w[o + rk] = w; }
+            }
+        } else {
+            if (lane == 0) L.bad = 1;
+        }
+    }
+    __syncthreads();
+    if (L.bad) {
+        // a sub-bucket of more than 1024 keys that are not all equal at this digit (heavily repeated
+        // keys next to others): sort the whole leaf with a bitonic network in LDS (rare; b is the source)
+        u32 P = 1;
+        while (P < n) P <<= 1;
+        for (u32 i = tid; i < P; i += KMC_MSD_THREADS) {
+            const bool in = i < n;
+            L.a_lo[i] = in ? L.b_lo[i] : ~0ull;
+            if (KW == 2) L.a_hi[i] = in ? L.b_hi[i] : ~0ull;
+            if (WEIGHTS) L.a_w[i] = in ? L.b_w[i] : 0ull;
+        }
+        __syncthreads();
+        for (u32 kk = 2; kk <= P; kk <<= 1) {
+            for (u32 jj = kk >> 1; jj > 0; jj >>= 1) {
+                for (u32 i = tid; i < P; i += KMC_MSD_THREADS) {
+                    const u32 ix = i ^ jj;
+                    if (ix > i) {
+                        const u64 al = L.a_lo[i], bl = L.a_lo[ix];
+                        const u64 ah = KW == 2 ? L.a_hi[i] : 0ull, bh = KW == 2 ? L.a_hi[ix] : 0ull;
+                        const bool up = (i & kk) == 0;
+                        const bool sw = up ? key_less(bh, bl, ah, al) : key_less(ah, al, bh, bl);
+                        if (sw) {
+                            L.a_lo[i] = bl; L.a_lo[ix] = al;
+                            if (KW == 2) { L.a_hi[i] = bh; L.a_hi[ix] = ah; }
+                            if (WEIGHTS) { const u64 wa = L.a_w[i]; L.a_w[i] = L.a_w[ix]; L.a_w[ix] = wa; }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+    // 4. run-length over the sorted image a[0..n): heads get the sum of their run's weights
+    //    (b is free: heads are compacted into it, then copied out)
+    for (u32 c0 = 0; c0 < n; c0 += KMC_MSD_THREADS * 4) {
+        // each thread owns 4 consecutive elements of this slab
+        const u32 i0 = c0 + tid * 4;
+        u32 nh = 0;
+        bool head[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const u32 i = i0 + e;
+            bool h = false;
+            if (i < n) h = i == 0 || L.a_lo[i] != L.a_lo[i - 1] || (KW == 2 && L.a_hi[i] != L.a_hi[i - 1]);
+            head[e] = h;
+            nh += h ? 1u : 0u;
+        }
+        u32 inc = nh;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+        __syncthreads();
+        if (lane == 63) L.wsum[wv] = inc;
+        __syncthreads();
+        u32 wbase = L.n_out;
+        for (u32 w = 0; w < wv; ++w) wbase += L.wsum[w];
+        u32 pos = wbase + inc - nh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const u32 i = i0 + e;
+            if (i < n && head[e]) {
+                u64 s = 0;
+                u32 j = i;
+                do { s += WEIGHTS ? L.a_w[j] : 1ull; ++j; } while (j < n && L.a_lo[j] == L.a_lo[i] && (KW == 1 || L.a_hi[j] == L.a_hi[i]));
+                L.b_lo[pos] = L.a_lo[i];
+                if (KW == 2) L.b_hi[pos] = L.a_hi[i];
+                L.b_w[pos] = s;
+                ++pos;
+            }
+        }
+        __syncthreads();
+        if (tid == KMC_MSD_THREADS - 1) L.n_out = pos;  // (the last thread's end = the slab's end)
+        __syncthreads();
+    }
+    const u32 n_out = L.n_out;
+    for (u32 i = tid; i < n_out; i += KMC_MSD_THREADS) {
+        t_lo[T.begin + i] = L.b_lo[i];
+        if (KW == 2) t_hi[T.begin + i] = L.b_hi[i];
+        t_cnt[T.begin + i] = L.b_w[i];
+    }
+    if (tid == 0) nd[t] = n_out;
+    (void)CAP;
+}
+
+// dense run: terminal t's nd[t] pairs move from its span of the staging arrays to base[t]
+template <int KW>
+__global__ void kmc_msd_gather_kernel(const MsdTerm* __restrict__ term, u32 n_term, const u32* __restrict__ nd, const u32* __restrict__ base,
+                                      const u64* __restrict__ s_hi0, const u64* __restrict__ s_lo0, const u64* __restrict__ s_hi1, const u64* __restrict__ s_lo1,
+                                      const u64* __restrict__ t_cnt, u64* __restrict__ o_hi, u64* __restrict__ o_lo, u64* __restrict__ o_cnt) {
+    // one wave per terminal
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (u32 t = wave; t < n_term; t += n_waves) {
+        const u32 src = term[t].begin, dst = base[t], m = nd[t];
+        const u64* const t_lo = term[t].parity ? s_lo0 : s_lo1;
+        const u64* const t_hi = term[t].parity ? s_hi0 : s_hi1;
+        for (u32 i = lane; i < m; i += 64) {
+            o_lo[dst + i] = t_lo[src + i];
+            if (KW == 2) o_hi[dst + i] = t_hi[src + i];
+            o_cnt[dst + i] = t_cnt[src + i];
+        }
+    }
+}

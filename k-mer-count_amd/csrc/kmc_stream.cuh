@@ -38,7 +38,7 @@
 // The first version of this kernel ran a probing loop per k-mer whose only exit was a wave-wide ballot:
 // with 64 lanes almost every trip had a straggler (190 SALU + 84 VALU wave-instructions per k-mer step,
 // 61 ms on the benchmark batch = 150 GB/s).
-#define KMC_STREAM_MISSBUF 128
+#define KMC_STREAM_MISSBUF 256
 template <int KW> struct StreamSlot;
 template <> struct StreamSlot<1> { u64 lo; };
 template <> struct StreamSlot<2> { u64 lo, hi; };
@@ -161,8 +161,10 @@ __device__ __forceinline__ u32 stream_count(StreamLds<KW>& L, int wv, u64 hi, u6
         m0 = h0 == hi && l0 == lo;
         m1 = h1 == hi && l1 == lo;
     }
+    // branch-free add: every lane adds to one of its home counters, 1 on a hit of a valid window and 0
+    // otherwise (a per-lane branch around the ds_add cost four scalar instructions per step)
     const bool hit = ok && (m0 || m1);
-    if (hit) atomicAdd(&L.cnt[h + (m0 ? 0u : 1u)], 1u);
+    atomicAdd(&L.cnt[h + (m0 ? 0u : 1u)], hit ? 1u : 0u);
     const bool miss = ok && !hit;
     const u64 mb = __builtin_amdgcn_ballot_w64(miss);
     if (mb != 0) {  // wave-uniform
@@ -384,10 +386,13 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         const bool ok = !((inv16 >> j) & 1);
                         if constexpr (SINK == 0) {
                             nk += ok;
-                            nbuf = stream_count<KW>(L, wv, khi, klo, ok, nbuf);
-                            if (nbuf > KMC_STREAM_MISSBUF - 64) {  // wave-uniform: no room for another full step
-                                nglobal += stream_drain<KW, CANON>(L, g, wv, lane, nbuf, k);
-                                nbuf = 0;
+                            const u32 nb1 = stream_count<KW>(L, wv, khi, klo, ok, nbuf);
+                            if (nb1 != nbuf) {  // wave-uniform: some lane missed
+                                nbuf = nb1;
+                                if (nbuf > KMC_STREAM_MISSBUF - 64) {  // no room for another full step
+                                    nglobal += stream_drain<KW, CANON>(L, g, wv, lane, nbuf, k);
+                                    nbuf = 0;
+                                }
                             }
                         } else {
                             o_lo[j] = ok ? klo : ~0ull;
@@ -397,11 +402,11 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                     }
                 }
             }
-            if constexpr (SINK == 0) {
-                if (nbuf) { nglobal += stream_drain<KW, CANON>(L, g, wv, lane, nbuf, k); nbuf = 0; }
-            }
             pw = wbe;
             pzb = zb;
+        }
+        if constexpr (SINK == 0) {
+            if (nbuf) { nglobal += stream_drain<KW, CANON>(L, g, wv, lane, nbuf, k); nbuf = 0; }
         }
     }
     nk = wave_sum_u64(nk);

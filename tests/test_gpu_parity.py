@@ -872,3 +872,25 @@ def test_auto_hands_over_long_high_cardinality_reads(kmc, oracle):
         assert st.algo_last == kmc.ALGO_SORT, st.algo_last   # it did switch
         assert st.launches_last >= 2
         assert t.equals(want), k
+
+
+@pytest.mark.parametrize("k,pool,n_rec", [(31, 0, 100_000), (63, 0, 60_000), (31, 1000, 150_000), (21, 40, 100_000), (5, 0, 50_000), (33, 200, 80_000)])
+def test_msd_sort_path_matches_oracle(kmc, oracle, k, pool, n_rec):
+    """KMC_ALGO_SORT = extraction + the hand-written MSD radix sort + run-length (kmc_msd.cuh), on inputs
+    from all-distinct (pool 0) to heavily repeated keys (small pools: equal-key segments, merged
+    leaves, sub-buckets larger than a wave), one- and two-word keys, both strands: the oracle's table."""
+    s = kmc.Synth(seed=11, pool=pool)
+    hb, ho = kmc.synth_reads_host(s, 3, n_rec)
+    for canonical in (True, False):
+        want = oracle.count_kmers(hb, ho, k, canonical, method=1)
+        with kmc.KmerCounter(k=k, canonical=canonical, algo=kmc.ALGO_SORT) as kc:
+            kc.add_batch(hb, ho)
+            got = kc.export()
+            assert kc.stats().algo_last == kmc.ALGO_SORT
+        assert got.equals(want), (k, pool, canonical, got.n_distinct, want.n_distinct)
+    # two batches into one ctx (two runs merged at finalize) == one batch
+    h = n_rec // 3
+    with kmc.KmerCounter(k=k, algo=kmc.ALGO_SORT) as kc:
+        kc.add_batch(hb[:h * 400], ho[:h + 1])
+        kc.add_batch(hb[h * 400:], ho[h:] - ho[h])
+        assert kc.export().equals(oracle.count_kmers(hb, ho, k, True, method=1))

@@ -2,7 +2,7 @@
 """Condenses a tools/profile_bench.sh output directory (gpurun_out/prof_<tag>) into the files
 kept under profiles/: <name>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary),
 <name>_pmc.json (per-launch counter averages of the count kernel, HBM traffic with the gfx950
-FETCH_SIZE correction), and r01_pmc_traffic.json which bench.py reads for roofline.traffic.
+FETCH_SIZE correction), and <round>_pmc_traffic_<algo>.json which bench.py reads for roofline.traffic.
 
 usage: tools/summarize_profile.py gpurun_out/prof_<tag> profiles/<name> <kernel substring> bases k algo
 """
@@ -51,5 +51,5 @@ out = {"kernel": kname, "full_batch_launches_traced": calls, "all_launches_trace
        "note": "FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for 16 B/lane streams); separate --pmc passes"}
 json.dump(out, open(dst + "_pmc.json", "w"), indent=1)
 json.dump({"workload_bases": bases, "k": k, "algo": algo, "hbm_bytes_per_launch": fetch + write,
-           "source": os.path.basename(dst) + "_pmc.json"}, open(os.path.join(os.path.dirname(dst), "r01_pmc_traffic.json"), "w"), indent=1)
+           "source": os.path.basename(dst) + "_pmc.json"}, open(os.path.join(os.path.dirname(dst), os.path.basename(dst).split("_")[0] + "_pmc_traffic_" + algo + ".json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
