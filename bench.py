@@ -39,7 +39,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5, help="untimed steps (the first ~3 run ~8%% slower: clock ramp-up)")
     ap.add_argument("--k", type=int, default=31)
-    ap.add_argument("--fasta-bytes", type=float, default=10e9, help="size of the synthetic FASTA text per GPU")
+    ap.add_argument("--fasta-bytes", type=float, default=10e9, help="size of the synthetic FASTA text per GPU (weak scaling)")
+    ap.add_argument("--total-fasta-bytes", type=float, default=0.0,
+                    help="strong scaling: ONE synthetic FASTA of this size, its records split over the ranks "
+                         "(BASELINE.json config 4: --gpus 8 --total-fasta-bytes 50e9 --seed 3); overrides --fasta-bytes")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--pool", type=int, default=10)
     ap.add_argument("--algo", default="auto", choices=["auto", "stream", "walk", "sort"])
@@ -78,8 +81,14 @@ def main():
 
     # ---- resident input: this rank's shard of the seeded record stream -------------------------
     synth = kmc.Synth(seed=args.seed, pool=args.pool)
-    n_rec, fasta_bytes = kmc.synth_records_for_bytes(synth, int(args.fasta_bytes))
-    first = rank * n_rec
+    strong = args.total_fasta_bytes > 0
+    if strong:
+        n_all, fasta_bytes = kmc.synth_records_for_bytes(synth, int(args.total_fasta_bytes))
+        first, n_rec = kdist.shard_range(n_all, rank, world)   # contiguous, balanced record shards
+    else:
+        n_rec, fasta_bytes = kmc.synth_records_for_bytes(synth, int(args.fasta_bytes))
+        first = rank * n_rec
+        n_all = n_rec * world
     read_len = synth.read_len
     n_bases = n_rec * read_len
     d_bases = torch.empty(n_bases + 64, dtype=torch.uint8, device=dev)
@@ -88,6 +97,7 @@ def main():
     torch.cuda.synchronize()
     k = args.k
     n_kmers = n_rec * (read_len - k + 1)
+    n_kmers_all = n_all * (read_len - k + 1)   # all ranks together
     algo = {"auto": kmc.ALGO_AUTO, "stream": kmc.ALGO_STREAM, "walk": kmc.ALGO_WALK, "sort": kmc.ALGO_SORT}[args.algo]
 
     # N > 1: both ctxs queue their kernels on ONE torch stream, the stream the RCCL collective is
@@ -171,25 +181,31 @@ def main():
         t = torch.tensor([own_nd, own_nt], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         reduced = {"distinct_all_owners": int(t[0].item()), "kmers_all_owners": int(t[1].item())}
-        if reduced["kmers_all_owners"] != n_kmers * world:
-            raise SystemExit(f"reduce mismatch: owners hold {reduced['kmers_all_owners']} k-mers, expected {n_kmers * world}")
+        if reduced["kmers_all_owners"] != n_kmers_all:
+            raise SystemExit(f"reduce mismatch: owners hold {reduced['kmers_all_owners']} k-mers, expected {n_kmers_all}")
 
     # ---- roofline of the dominant kernel (this rank's launches; every rank runs the same shape) --
     algo_bytes = n_bases + 8 * (n_rec + 1)  # 1 B/base ASCII + the offsets array
     k_ms = float(np.mean(kernel_ms)) if kernel_ms else float("nan")
     achieved = algo_bytes / (k_ms * 1e-3) / 1e9
+    # HBM bytes per launch from the PMC passes of tools/profile_bench.sh (FETCH_SIZE / WRITE_SIZE in their
+    # own rocprofv3 runs, gfx950 correction applied by tools/summarize_profile.py); only reported when a
+    # committed profile matches this exact workload and algorithm
     traffic = None
-    prof = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(prof):
+    import glob
+    for prof in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")), reverse=True):
         try:
             pj = json.load(open(prof))
             if pj.get("workload_bases") == n_bases and pj.get("k") == k and pj.get("algo") == algo_used:
                 traffic = pj.get("hbm_bytes_per_launch")
+                break
         except Exception:
-            traffic = None
+            pass
+    dominant = {"walk": "kmc_walk_kernel", "stream": "kmc_stream_kernel",
+                "sort": "sort pipeline: kmc_stream_kernel<SINK=1> (extract) + kmc_msd_{hist,scan,scatter,leaf,gather}_kernel"}.get(algo_used, "?")
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": f"kmc_{algo_used}_kernel", "kernel_ms": round(k_ms, 4),
+                "kernel": dominant, "kernel_ms": round(k_ms, 4),
                 "launches_per_step": int(round(float(np.mean(launches)))) if launches else None,
                 "kernel_ms_cold_memo": round(float(np.mean(cold_ms)), 4) if cold_ms else None,
                 "algorithmic_bytes_per_step": algo_bytes}
@@ -246,7 +262,7 @@ def main():
         cpu["other_views"] = extra
 
     if rank == 0:
-        total_kmers = n_kmers * world * args.steps
+        total_kmers = n_kmers_all * args.steps
         out = {
             "metric": "k-mers/sec (whole node) on synthetic FASTA, k=%d; counts bit-exact vs ref" % k,
             "value": round(total_kmers / elapsed, 1),
@@ -256,13 +272,13 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "%.0f GB synthetic FASTA (random_fasta_generator.py distribution, seed %d, pool %d), "
-                                   "k=%d, %s, %dxMI355X" % (fasta_bytes / 1e9, args.seed, args.pool, k,
-                                                            "forward" if args.forward else "canonical", world),
+            "config": {"workload": "%.0f GB synthetic FASTA%s (random_fasta_generator.py distribution, seed %d, pool %d), "
+                                   "k=%d, %s, %dxMI355X" % (fasta_bytes / 1e9, " in total, records split over the ranks" if strong else (" per GPU" if world > 1 else ""),
+                                                            args.seed, args.pool, k, "forward" if args.forward else "canonical", world),
                        "records_per_gpu": n_rec, "bases_per_gpu": n_bases, "kmers_per_gpu": n_kmers,
                        "distinct": int(reduced["distinct_all_owners"]) if reduced else int(nd), "algo": algo_used, "sharding": "records, one shard per GPU; RCCL table reduce (one all-gather of fixed-size slabs)"
                        if world > 1 else "single GPU", "reduced": reduced, "exact_full_size_check": exact_full},

@@ -131,7 +131,12 @@ int kmc_add_batch(kmc_ctx* ctx, const uint8_t* bases, const uint64_t* offsets, u
 /* Same, for buffers already resident in this ctx's GPU memory (HBM-resident timing, pipelines
  * that parse into pinned/device memory).  d_bases must be 16-byte aligned and readable up to the
  * next 16-byte boundary past the last base.  max_read_len: longest read in the batch, or 0 if
- * unknown (then it is computed on the device).  Asynchronous on the ctx stream. */
+ * unknown (then it is computed on the device).  Asynchronous on the ctx stream.  The buffers must stay
+ * valid and unchanged until the next call on this ctx that synchronises (kmc_add_batch*, kmc_finalize,
+ * kmc_poll, kmc_export): the batch may go out in one launch sized by what earlier batches looked like, and
+ * if that prediction proves wrong (far more distinct k-mers than the table and its spill area hold) the
+ * library puts the table back and counts the affected part of the batch again by sorting -- nothing is
+ * dropped and no KMC_ERR_CAPACITY is raised. */
 int kmc_add_batch_device(kmc_ctx* ctx, const void* d_bases, const void* d_offsets,
                          uint64_t n_reads, uint64_t n_bases, uint64_t max_read_len);
 
@@ -186,6 +191,11 @@ int kmc_merge_slabs_device(kmc_ctx* ctx, const void* d_slabs, uint32_t n_slabs, 
  * kmc_finalize does on the way, for callers that reset a ctx without finalizing it (multi-GPU
  * reduce: the live table is packed and shipped, only the owner's table is finalized). */
 int kmc_poll(kmc_ctx* ctx);
+
+/* Wait until everything queued on the ctx's stream has finished (nothing else: no counters are read).
+ * For callers that hand buffers written by ctx kernels to another stream or library (the RCCL
+ * all-gather of a slab packed on a ctx-owned stream). */
+int kmc_sync(kmc_ctx* ctx);
 
 /* How KMC_ALGO_WALK cuts a read of read_len bases into pieces of at most 416 bases that overlap by
  * k-1 (every window of the read lies in exactly one piece): the number of pieces, and, for the

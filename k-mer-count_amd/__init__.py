@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "kmc_synth_reads_host", "kmc_synth_reads_device", "kmc_synth_write_fasta",
     "kmc_slab_words", "kmc_pack_slab_device", "kmc_merge_slabs_device", "kmc_forget_source",
     "kmc_fasta_stream_open", "kmc_fasta_stream_next", "kmc_fasta_stream_close", "kmc_poll",
-    "kmc_count_file_multi", "kmc_read_pieces",
+    "kmc_count_file_multi", "kmc_read_pieces", "kmc_sync",
 ]
 
 _lib = None
@@ -142,6 +142,7 @@ def lib() -> C.CDLL:
     L.kmc_merge_slabs_device.argtypes = [vp, vp, u32, u64, u32, u32]
     L.kmc_forget_source.argtypes = [vp, i32]
     L.kmc_poll.argtypes = [vp]
+    L.kmc_sync.argtypes = [vp]
     L.kmc_read_pieces.argtypes = [u64, i32, vp, vp, u64]
     L.kmc_read_pieces.restype = u64
     L.kmc_count_file.argtypes = [vp, C.c_char_p, pu64, pu64]
@@ -396,6 +397,10 @@ class KmerCounter:
     def poll(self):
         """Synchronise and read the device counters (stats, launch-planner history) without finalizing."""
         self._chk(self._L.kmc_poll(self._h))
+
+    def sync(self):
+        """Wait for everything queued on the ctx's stream (no counters are read)."""
+        self._chk(self._L.kmc_sync(self._h))
 
     def forget_source(self, memo: bool = True, history: bool = False):
         self._chk(self._L.kmc_forget_source(self._h, (1 if memo else 0) | (2 if history else 0)))

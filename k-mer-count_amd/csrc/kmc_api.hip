@@ -77,9 +77,9 @@ struct kmc_ctx {
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
     DevBuf s_lo[2], s_hi[2], s_flags, s_pos, s_head;
     // hand-written MSD radix sort (kmc_msd.cuh): per-range histograms, segment lists, terminals
-    DevBuf m_hist, m_stot, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_cnt, m_w[2];
+    DevBuf m_hist, m_stot, m_bsum, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_cnt, m_w[2];
     MsdCtl* h_ctl = nullptr;  // pinned mirror of the sort's device counters
-    struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0, cap = 0; };
+    struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0, cap = 0; u64 total = 0; bool total_known = false; };
     std::vector<Run> runs;       // live runs
     std::vector<Run> run_pool;   // buffers of dropped runs, reused (multi-GB hipMalloc/hipFree per batch is slow)
     const u64 *v_hi = nullptr, *v_lo = nullptr, *v_cnt = nullptr;  // the sorted view of the last finalize
@@ -102,6 +102,25 @@ struct kmc_ctx {
     bool b_open = false; double b_rho_max = 0.0; u64 b_occ0 = 0, b_kmers = 0;  // the batch whose last launch is still unobserved
     double rho_max = 0.0;  // largest observed (new distinct) / (k-mers) over a sub-batch
     int n_cu = 256;
+    // A launch sized by a prediction (more k-mers than the table and spill area absorb for certain) is
+    // "risky": the table is saved first, and if the spill area overflows the table is put back and the
+    // rest of the batch is counted by the sort path, which needs no table (recover_overflow).
+    struct Risky {
+        bool armed = false;
+        int mode = 0;                 // 1: entries listed in occ_list; 2: whole table copied
+        const uint8_t* d_bases = nullptr; const u64* d_offsets = nullptr; u64 n_reads = 0, n_bases = 0;
+        u64 base_from = 0;            // first base position the risky launch covers ...
+        const u64* d_from = nullptr;  // ... or where to read it on the device (end of the last piece walked before)
+        u64 ctr[KMC_CTR_N] = {0};     // the device counters before the launch
+    } risky;
+    DevBuf snap_hi, snap_lo, snap_cnt, snap_n, snap_occ;
+    // second-level memo of the walk kernel: (k+16)-mer table (kmc_walk.cuh), k <= 47
+    Table sk;
+    u64* d_sk_counters = nullptr;
+    u64* h_sk_counters = nullptr;   // pinned mirror (valid after a poll)
+    u64 *sk_spill_hi = nullptr, *sk_spill_lo = nullptr, *sk_spill_cnt = nullptr;
+    u64 sk_spill_cap = 0;
+    bool recovered = false;  // the last poll found an overflow and recovered: the batch in flight is complete
 };
 
 namespace {
@@ -187,6 +206,8 @@ int take_run(kmc_ctx* c, u64 cap, kmc_ctx::Run* out) {
         *out = c->run_pool[(size_t)best];
         c->run_pool.erase(c->run_pool.begin() + best);
         out->n = 0;
+        out->total = 0;
+        out->total_known = false;
         return KMC_OK;
     }
     if (!c->run_pool.empty()) {  // nothing fits: recycle the memory of the largest pooled buffer
@@ -223,6 +244,51 @@ GTable gtable_of(const kmc_ctx* c, const Table& t) {
     return g;
 }
 
+GTable sk_table_of(const kmc_ctx* c) {
+    GTable g{};
+    if (!c->sk.lo) return g;  // key_lo == nullptr: no second-level memo
+    g.key_hi = c->sk.hi;
+    g.key_lo = c->sk.lo;
+    g.count = c->sk.cnt;
+    g.capmask = c->sk.cap - 1;
+    g.counters = c->d_sk_counters;
+    g.spill_hi = c->sk_spill_hi;
+    g.spill_lo = c->sk_spill_lo;
+    g.spill_cnt = c->sk_spill_cnt;
+    g.spill_cap = c->sk_spill_cap;
+    g.occ_list = nullptr;
+    g.occ_list_cap = 0;
+    return g;
+}
+
+int sk_clear(kmc_ctx* c) {
+    if (!c->sk.lo) return KMC_OK;
+    HIPCHK(c, hipMemsetAsync(c->sk.hi, 0xFF, c->sk.cap * sizeof(u64), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->sk.lo, 0, c->sk.cap * sizeof(u64), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->sk.cnt, 0, c->sk.cap * sizeof(u64), c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_sk_counters, 0, KMC_CTR_N * sizeof(u64), c->stream));
+    memset(c->h_sk_counters, 0, KMC_CTR_N * sizeof(u64));
+    return KMC_OK;
+}
+
+// the walk kernel's (k+16)-mer table: allocated at the first walk launch of a ctx with k <= 47
+int sk_ensure(kmc_ctx* c) {
+    if (c->sk.lo || c->cfg.mode != KMC_MODE_CONTIG || c->cfg.k > KMC_SK_MAX_K) return KMC_OK;
+    u64 cap = 1ull << 24;
+    if (const char* e = getenv("KMC_SK_SLOTS")) { u64 v = strtoull(e, nullptr, 10); if (v >= 1024) { cap = 1; while (cap < v) cap <<= 1; } }
+    c->sk.cap = cap;
+    HIPCHK(c, hipMalloc((void**)&c->sk.hi, cap * sizeof(u64)));
+    HIPCHK(c, hipMalloc((void**)&c->sk.lo, cap * sizeof(u64)));
+    HIPCHK(c, hipMalloc((void**)&c->sk.cnt, cap * sizeof(u64)));
+    HIPCHK(c, hipMalloc((void**)&c->d_sk_counters, KMC_CTR_N * sizeof(u64)));
+    HIPCHK(c, hipHostMalloc((void**)&c->h_sk_counters, KMC_CTR_N * sizeof(u64)));
+    c->sk_spill_cap = std::max<u64>(cap / 64, 4096);
+    HIPCHK(c, hipMalloc((void**)&c->sk_spill_hi, c->sk_spill_cap * sizeof(u64)));
+    HIPCHK(c, hipMalloc((void**)&c->sk_spill_lo, c->sk_spill_cap * sizeof(u64)));
+    HIPCHK(c, hipMalloc((void**)&c->sk_spill_cnt, c->sk_spill_cap * sizeof(u64)));
+    return sk_clear(c);
+}
+
 u64 next_pow2(u64 v) {
     u64 p = 1;
     while (p < v) p <<= 1;
@@ -243,6 +309,7 @@ auto kw_dispatch(int KW, F1 f1, F2 f2) { return KW == 1 ? f1() : f2(); }
 // read the device counters (synchronises the stream)
 int poll(kmc_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, KMC_CTR_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    if (c->sk.lo) HIPCHK(c, hipMemcpyAsync(c->h_sk_counters, c->d_sk_counters, KMC_CTR_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->pending = false;
     c->batch_pending = false;
@@ -254,6 +321,8 @@ int poll(kmc_ctx* c) {
         u64 d = c->h_counters[KMC_CTR_BADBASE], n = c->h_counters[KMC_CTR_KMERS];
         u64 dd = d - c->direct_seen, dn = n - c->kmers_seen;
         if (d >= c->direct_seen && n > c->kmers_seen && (c->st.algo_last == KMC_ALGO_WALK || c->st.algo_last == KMC_ALGO_STREAM)) c->walk_overflowed = dd * 20 > dn;
+        // the second-level memo more than half full: this input has too many distinct (k+16)-mers for it
+        if (c->sk.lo && (c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL]) * 2 > c->sk.cap) c->walk_overflowed = true;
         c->direct_seen = d;
         c->kmers_seen = n;
     }
@@ -268,6 +337,8 @@ int poll(kmc_ctx* c) {
     }
     return KMC_OK;
 }
+
+int recover_overflow(kmc_ctx* c);
 
 int grow_to(kmc_ctx* c, u64 newcap) {
     Table nt;
@@ -291,10 +362,13 @@ int grow_to(kmc_ctx* c, u64 newcap) {
 int settle(kmc_ctx* c) {
     for (int iter = 0; iter < 40; ++iter) {
         u64 occ = c->h_counters[KMC_CTR_OCCUPIED], spill = c->h_counters[KMC_CTR_SPILL], err = c->h_counters[KMC_CTR_ERR];
+        if (c->sk.lo && c->h_sk_counters[KMC_CTR_ERR]) err |= (c->h_sk_counters[KMC_CTR_ERR] & 2) ? 2 : 1;  // the (k+16)-mer table dropped pairs
         if (err & 4) return fail(c, KMC_ERR_ALPHABET, "Unexpected charactor appears in a sequence (reference mode accepts ACGT only)");
         if (err & 2) return fail(c, KMC_ERR_HIP, "table insert gave up after too many retries (internal error)");
+        if (err == 1 && c->risky.armed) return recover_overflow(c);  // a prediction was wrong: put the table back, count that part by sorting
         if (err) return fail(c, KMC_ERR_CAPACITY, "count table and spill area exhausted (capacity %llu slots, %llu spilled); raise capacity_hint",
                              (unsigned long long)c->tab.cap, (unsigned long long)spill);
+        c->risky.armed = false;  // (whatever was predicted has been absorbed)
         if (!spill && occ * 2 <= c->tab.cap) return KMC_OK;
         u64 need = (occ + spill) * 2;
         u64 newcap = c->tab.cap;
@@ -395,7 +469,6 @@ int launch_extract(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64
     int grid = (int)((waves + KMC_STREAM_WAVES - 1) / KMC_STREAM_WAVES);
     GTable g = gtable_of(c, c->tab);
     const bool canon = c->cfg.canonical != 0;
-    { int rc = launch_begin(c); if (rc) return rc; }
 #define LAUNCH_EXTRACT(KWV, CAN)                                                                             \
     hipLaunchKernelGGL((kmc_stream_kernel<KWV, CAN, 1>), dim3(grid), dim3(KMC_STREAM_THREADS), 0, c->stream, \
                        d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, cpw, range_begin, g, out_hi, out_lo)
@@ -403,7 +476,7 @@ int launch_extract(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64
     else { if (canon) LAUNCH_EXTRACT(2, true); else LAUNCH_EXTRACT(2, false); }
 #undef LAUNCH_EXTRACT
     HIPCHK(c, hipGetLastError());
-    return launch_end(c);
+    return KMC_OK;
 }
 
 template <typename K, typename V>
@@ -531,6 +604,7 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     MSD_ENSURE(c->m_nd, term_cap * sizeof(u32));
     MSD_ENSURE(c->m_base, term_cap * sizeof(u32));
     MSD_ENSURE(c->m_ctl, sizeof(MsdCtl));
+    MSD_ENSURE(c->m_bsum, (std::max<u64>(n_words, term_cap) / KMC_SCAN_PER_BLOCK + 2) * sizeof(u32));
     MSD_ENSURE(c->m_cnt, n * sizeof(u64));
 #undef MSD_ENSURE
     if (!c->h_ctl) HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, sizeof(MsdCtl)));
@@ -541,10 +615,10 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     HIPCHK(c, hipMemcpyAsync(c->m_seg[0].p, &root, sizeof(root), hipMemcpyHostToDevice, c->stream));
     u32 n_seg = 1;
     int cur = 0, par = 0;
-    const int levels = kb <= 8 ? 1 : (int)((kb + 7) / 8);
+    const int levels = kb <= KMC_MSD_BITS ? 1 : (int)((kb + KMC_MSD_BITS - 1) / KMC_MSD_BITS);
     for (int l = 0; l < levels && n_seg; ++l) {
-        const int hi_bit = (int)kb - 8 * l;
-        const int width = hi_bit < 8 ? hi_bit : 8;
+        const int hi_bit = (int)kb - KMC_MSD_BITS * l;
+        const int width = hi_bit < KMC_MSD_BITS ? hi_bit : KMC_MSD_BITS;
         const int shift = hi_bit - width;
         const u32 mask = (1u << width) - 1u;
         const int last = shift == 0 ? 1 : 0;
@@ -560,15 +634,19 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
         else hipLaunchKernelGGL(kmc_msd_hist_kernel<2>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, shi, slo, (const MsdSeg*)seg, n_seg, (const u32*)first, shift, mask, (int)kb, l == 0 ? 1 : 0,
                                 (u32*)c->m_hist.p, (u64*)c->m_rmin.p, (u64*)c->m_rmax.p, (const MsdCtl*)ctl);
         HIPCHK(c, hipMemsetAsync(&ctl->n_next, 0, sizeof(u32), c->stream));
-        const u32 S = n_seg <= 4096 ? 65u : 1u;  // few segments = long ones: one digit column per wave
+        const u32 S = n_seg <= 4096 ? 64u : 1u;  // few segments = long ones: digit columns spread over 64 workgroups
         hipLaunchKernelGGL(kmc_msd_scan_a_kernel, dim3(n_seg * S), dim3(KMC_MSD_THREADS), 0, c->stream, n_seg, S, (const u32*)first, (u32*)c->m_hist.p, (u32*)c->m_stot.p);
-        hipLaunchKernelGGL(kmc_msd_scan_kernel, dim3(n_seg), dim3(KMC_MSD_THREADS), 0, c->stream, (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)c->m_stot.p,
+        hipLaunchKernelGGL(kmc_msd_scan_kernel, dim3(n_seg), dim3(KMC_MSD_ND), 0, c->stream, (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)c->m_stot.p,
                            (const u64*)c->m_rmin.p, (const u64*)c->m_rmax.p, (u32*)c->m_cbase.p, (u32*)c->m_skip.p, last, l == 0 ? 1 : 0, leaf_cap, (u32)par,
                            next, (u32)max_seg, (MsdTerm*)c->m_term.p, (u32)term_cap, (unsigned long long*)c->m_bitmap.p, ctl);
 #define MSD_SCATTER(KWV, WV)                                                                                                              \
-        hipLaunchKernelGGL((kmc_msd_scatter_kernel<KWV, WV>), dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, shi, slo, sw, dhi, dlo, dw, \
-                           (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)c->m_hist.p, (const u32*)c->m_cbase.p, (const u32*)c->m_skip.p, \
-                           shift, mask, (int)kb, l == 0 ? 1 : 0, (const MsdCtl*)ctl)
+        do {                                                                                                                              \
+            static bool attr = false;                                                                                                     \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_msd_scatter_kernel<KWV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdScatterLds<KWV, WV>)); attr = true; } \
+            hipLaunchKernelGGL((kmc_msd_scatter_kernel<KWV, WV>), dim3(grid), dim3(1024), sizeof(MsdScatterLds<KWV, WV>), c->stream, shi, slo, sw, dhi, dlo, dw, \
+                               (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)c->m_hist.p, (const u32*)c->m_cbase.p, (const u32*)c->m_skip.p, \
+                               shift, mask, (int)kb, l == 0 ? 1 : 0, (const MsdCtl*)ctl);                                                 \
+        } while (0)
         if (KW == 1) { if (weights) MSD_SCATTER(1, true); else MSD_SCATTER(1, false); }
         else { if (weights) MSD_SCATTER(2, true); else MSD_SCATTER(2, false); }
 #undef MSD_SCATTER
@@ -583,7 +661,12 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     const u32 n_term = c->h_ctl->n_term;
     if (!n_term) return KMC_OK;  // nothing but filler
     // terminals in position order, their pairs, the dense run
-    hipLaunchKernelGGL(kmc_msd_bitrank_kernel, dim3(1), dim3(1024), 0, c->stream, (const unsigned long long*)c->m_bitmap.p, (u32)n_words, (u32*)c->m_rank.p);
+    {   // rank of every bitmap word = exclusive prefix of the popcounts
+        const u32 nb = (u32)((n_words + KMC_SCAN_PER_BLOCK - 1) / KMC_SCAN_PER_BLOCK);
+        hipLaunchKernelGGL(kmc_scan_sums_kernel<1>, dim3(nb), dim3(256), 0, c->stream, (const void*)c->m_bitmap.p, (u32)n_words, (u32*)c->m_bsum.p);
+        hipLaunchKernelGGL(kmc_scan_top_kernel, dim3(1), dim3(1024), 0, c->stream, (u32*)c->m_bsum.p, nb, &ctl->scan_total);
+        hipLaunchKernelGGL(kmc_scan_final_kernel<1>, dim3(nb), dim3(256), 0, c->stream, (const void*)c->m_bitmap.p, (u32)n_words, (const u32*)c->m_bsum.p, (u32*)c->m_rank.p);
+    }
     hipLaunchKernelGGL(kmc_msd_order_kernel, dim3(grid_for(c, n_term, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_term.p, n_term,
                        (const unsigned long long*)c->m_bitmap.p, (const u32*)c->m_rank.p, (MsdTerm*)c->m_ord.p);
     u64* t_cnt0 = (u64*)c->m_cnt.p;  // pair staging: counts (keys are staged in the key buffers themselves)
@@ -598,7 +681,12 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     if (KW == 1) { if (weights) MSD_LEAF(1, true); else MSD_LEAF(1, false); }
     else { if (weights) MSD_LEAF(2, true); else MSD_LEAF(2, false); }
 #undef MSD_LEAF
-    hipLaunchKernelGGL(kmc_msd_scan_nd_kernel, dim3(1), dim3(1024), 0, c->stream, (const u32*)c->m_nd.p, n_term, (u32*)c->m_base.p, ctl);
+    {   // base[t] = exclusive prefix of the terminals' pair counts
+        const u32 nb = (n_term + KMC_SCAN_PER_BLOCK - 1) / KMC_SCAN_PER_BLOCK;
+        hipLaunchKernelGGL(kmc_scan_sums_kernel<0>, dim3(nb), dim3(256), 0, c->stream, (const void*)c->m_nd.p, n_term, (u32*)c->m_bsum.p);
+        hipLaunchKernelGGL(kmc_scan_top_kernel, dim3(1), dim3(1024), 0, c->stream, (u32*)c->m_bsum.p, nb, &ctl->n_pairs);
+        hipLaunchKernelGGL(kmc_scan_final_kernel<0>, dim3(nb), dim3(256), 0, c->stream, (const void*)c->m_nd.p, n_term, (const u32*)c->m_bsum.p, (u32*)c->m_base.p);
+    }
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(MsdCtl), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -607,6 +695,8 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     rc = take_run(c, std::max<u64>(n_pairs, 1), &run);
     if (rc) return rc;
     run.n = n_pairs;
+    run.total = c->h_ctl->n_valid;      // every valid key counts once (no weights): the run's counts sum to this
+    run.total_known = !weights;
     c->runs.push_back(run);
     if (KW == 1) hipLaunchKernelGGL(kmc_msd_gather_kernel<1>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, (const u32*)c->m_nd.p, (const u32*)c->m_base.p,
                                     (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1], (const u64*)t_cnt0, run.hi, run.lo, run.cnt);
@@ -630,16 +720,106 @@ int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
             if (rc) return rc;
             if (c->KW == 2) { rc = ensure(c, c->s_hi[i], (size_t)n * sizeof(u64)); if (rc) return rc; }
         }
-        int rc = launch_extract(c, d_bases, d_offsets, n_reads, n_bases, cb, ce, range_begin, (u64*)c->s_hi[0].p, (u64*)c->s_lo[0].p);
+        // (the event pair brackets the whole pipeline of the sub-batch: extraction, sort levels, leaves, gather)
+        int rc = launch_begin(c);
+        if (rc) return rc;
+        rc = launch_extract(c, d_bases, d_offsets, n_reads, n_bases, cb, ce, range_begin, (u64*)c->s_hi[0].p, (u64*)c->s_lo[0].p);
         if (rc) return rc;
         u64* const khi[2] = {(u64*)c->s_hi[0].p, (u64*)c->s_hi[1].p};
         u64* const klo[2] = {(u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p};
         u64* const kwt[2] = {nullptr, nullptr};
         rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen);
         if (rc) return rc;
+        rc = launch_end(c);
+        if (rc) return rc;
     }
     c->pending = true;
     return KMC_OK;
+}
+
+// Save the table in front of a risky launch (see kmc_ctx::Risky).  Returns false when the table is too
+// large to be saved cheaply: the caller then keeps the launch within what is certain to fit.
+bool arm_risky(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 base_from, const u64* d_from) {
+    const u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
+    kmc_ctx::Risky& r = c->risky;
+    GTable g = gtable_of(c, c->tab);
+    if (occ <= KMC_OCC_LIST_CAP && c->occ_list && c->h_counters[KMC_CTR_SPILL] == 0) {
+        const size_t nb = (size_t)KMC_OCC_LIST_CAP * sizeof(u64);
+        if (ensure(c, c->snap_lo, nb) || ensure(c, c->snap_cnt, nb) || ensure(c, c->snap_n, 64) || (c->KW == 2 && ensure(c, c->snap_hi, nb))) return false;
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_snapshot_kernel<1>, dim3(32), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->snap_lo.p, (u64*)c->snap_cnt.p, (u64*)c->snap_n.p);
+        else hipLaunchKernelGGL(kmc_snapshot_kernel<2>, dim3(32), dim3(256), 0, c->stream, g, (u64*)c->snap_hi.p, (u64*)c->snap_lo.p, (u64*)c->snap_cnt.p, (u64*)c->snap_n.p);
+        if (hipGetLastError() != hipSuccess) return false;
+        r.mode = 1;
+    } else if (c->tab.cap <= (16ull << 20)) {
+        const size_t nb = (size_t)c->tab.cap * sizeof(u64);
+        if (ensure(c, c->snap_lo, nb) || ensure(c, c->snap_cnt, nb) || (c->KW == 2 && ensure(c, c->snap_hi, nb)) || ensure(c, c->snap_occ, (size_t)KMC_OCC_LIST_CAP * sizeof(u64))) return false;
+        bool ok = hipMemcpyAsync(c->snap_lo.p, c->tab.lo, nb, hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
+                  hipMemcpyAsync(c->snap_cnt.p, c->tab.cnt, nb, hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
+                  hipMemcpyAsync(c->snap_occ.p, c->occ_list, (size_t)KMC_OCC_LIST_CAP * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+        if (ok && c->KW == 2) ok = hipMemcpyAsync(c->snap_hi.p, c->tab.hi, nb, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); return false; }
+        r.mode = 2;
+    } else {
+        return false;
+    }
+    r.armed = true;
+    r.d_bases = d_bases; r.d_offsets = d_offsets; r.n_reads = n_reads; r.n_bases = n_bases;
+    r.base_from = base_from; r.d_from = d_from;
+    memcpy(r.ctr, c->h_counters, sizeof(r.ctr));
+    return true;
+}
+
+// The spill area overflowed in a risky launch: some (key, count) pairs were dropped, so the table is put
+// back as it was in front of that launch and everything from the launch's first base position to the
+// end of the batch is counted by the sort path (extract, sort, run-length: no table, any cardinality).
+int recover_overflow(kmc_ctx* c) {
+    kmc_ctx::Risky r = c->risky;
+    c->risky.armed = false;
+    GTable g = gtable_of(c, c->tab);
+    u64 ctr[KMC_CTR_N];
+    memcpy(ctr, r.ctr, sizeof(ctr));
+    ctr[KMC_CTR_ERR] = 0;
+    ctr[KMC_CTR_SPILL] = 0;
+    ctr[KMC_CTR_FASTFIN] = 0;  // (a speculative finalize queued in front of this poll looked at the overflowed table)
+    if (r.mode == 1) {
+        u64 n_snap = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_snap, c->snap_n.p, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n_snap == ~0ull) return fail(c, KMC_ERR_CAPACITY, "count table and spill area exhausted and the table could not be restored; raise capacity_hint");
+        const int grid = grid_for(c, c->tab.cap, 256);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g);
+        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g);
+        ctr[KMC_CTR_OCCUPIED] = 0;  // (the merge below claims the slots again and counts them)
+        HIPCHK(c, hipMemcpyAsync(c->d_counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, c->stream));
+        if (n_snap) {
+            if (c->KW == 1) hipLaunchKernelGGL(kmc_merge_pairs_kernel<1>, dim3(grid_for(c, n_snap, 256)), dim3(256), 0, c->stream, g, (const u64*)nullptr, (const u64*)c->snap_lo.p, (const u64*)c->snap_cnt.p, n_snap);
+            else hipLaunchKernelGGL(kmc_merge_pairs_kernel<2>, dim3(grid_for(c, n_snap, 256)), dim3(256), 0, c->stream, g, (const u64*)c->snap_hi.p, (const u64*)c->snap_lo.p, (const u64*)c->snap_cnt.p, n_snap);
+        }
+        HIPCHK(c, hipGetLastError());
+    } else {
+        const size_t nb = (size_t)c->tab.cap * sizeof(u64);
+        HIPCHK(c, hipMemcpyAsync(c->tab.lo, c->snap_lo.p, nb, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->tab.cnt, c->snap_cnt.p, nb, hipMemcpyDeviceToDevice, c->stream));
+        if (c->KW == 2) HIPCHK(c, hipMemcpyAsync(c->tab.hi, c->snap_hi.p, nb, hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->occ_list, c->snap_occ.p, (size_t)KMC_OCC_LIST_CAP * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, c->stream));
+    }
+    { int rs = sk_clear(c); if (rs) return rs; }  // (its counts belong to the launch that is being undone)
+    u64 from = r.base_from;
+    if (r.d_from) HIPCHK(c, hipMemcpyAsync(&from, r.d_from, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (ctr[] and `from` are stack memory)
+    memcpy(c->h_counters, ctr, sizeof(ctr));
+    c->h_counters[KMC_CTR_OCCUPIED] = r.ctr[KMC_CTR_OCCUPIED];
+    c->direct_seen = ctr[KMC_CTR_BADBASE];
+    c->kmers_seen = ctr[KMC_CTR_KMERS];
+    // this data source is not what the history said: forget it, and leave the per-occurrence kernels alone
+    c->rho_hist = -1.0;
+    c->rho_last = 0.0;
+    c->b_open = false;
+    if (c->cfg.algo == KMC_ALGO_AUTO) c->prefer_sort = true;
+    c->st.algo_last = KMC_ALGO_SORT;
+    c->recovered = true;
+    return run_sort_path(c, r.d_bases, r.d_offsets, r.n_reads, r.n_bases, from);
 }
 
 // pieces of at most KMC_WALK_MAX_READ bases for a batch with longer reads (kmc_walk.cuh): vr_reads = [starts | ends]
@@ -672,6 +852,7 @@ int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
 
 int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len) {
     if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
+    c->recovered = false;
     c->sorted_valid = false;
     c->st.n_reads += n_reads;
     c->st.n_bases += n_bases;
@@ -707,15 +888,20 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
         // ramp up (x16 at most) using the observed ratio rho = new keys per k-mer.  With history
         // (the previous batch on this ctx, kept across kmc_reset) the batch goes out in as few
         // launches as 8 x the predicted number of new keys allows -- one for the benchmark input.
-        // If a prediction is ever wrong enough to exhaust table AND spill area the call fails with
-        // KMC_ERR_CAPACITY (nothing is silently dropped).
+        // A launch larger than what is certain to fit is "risky": the table is saved in front of it
+        // (arm_risky) and, should the prediction be wrong enough to exhaust table AND spill area, the
+        // next poll puts the table back and counts the rest of the batch by sorting (recover_overflow):
+        // nothing is dropped and nothing fails.  The caller's device buffers must therefore stay valid
+        // until the next call on the ctx that synchronises (kmc.h, kmc_add_batch_device).
         double batch_rho_max = 0.0;
+        u64 plan_safe = 0;  // units of the last plan() that fit for certain
         c->b_occ0 = c->h_counters[KMC_CTR_OCCUPIED];
         c->b_kmers = std::max<u64>(n_bases, 1);
         auto plan = [&](u64 units_left, u64 kmers_per_unit, u64 prev) -> u64 {
             u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
             u64 freeslots = (c->tab.cap * 7 / 10 > occ ? c->tab.cap * 7 / 10 - occ : 0) + c->spill_cap / 2;
             u64 safe = std::max<u64>(freeslots / kmers_per_unit, 1);
+            plan_safe = safe;
             u64 take = safe;
             if (prev) {
                 double opt = (double)freeslots / (4.0 * std::max(c->rho_last, 1e-9)) / (double)kmers_per_unit;
@@ -730,6 +916,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
         auto observe = [&](u64 occ_before, u64 units, u64 kmers_per_unit) -> int {
             int r = poll_and_settle(c);
             if (r) return r;
+            if (c->recovered) return KMC_OK;
             u64 occ_after = c->h_counters[KMC_CTR_OCCUPIED];
             double rho = (double)(occ_after > occ_before ? occ_after - occ_before : 0) / ((double)units * (double)kmers_per_unit);
             c->rho_last = rho;
@@ -746,28 +933,33 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
         };
         const bool lr = c->cfg.mode == KMC_MODE_LR;
         if (lr) {
-            // Reference mode: every window start contributes up to 61 keys (27 + gap + 27 for sizes
-            // 80..=140).  Ranges of window starts go through the same planner as the contiguous
-            // kernels (61 "k-mers" per position), so the table follows the number of DISTINCT keys
-            // (the first version grew it to the worst case 2 x 61 x bases before its single launch:
-            // 268 M slots for 1.6 M bases with 2 M distinct keys -- 20 of that run's 25 ms went into
-            // allocating, clearing and compacting an almost empty table).
-            const u64 per = KMC_LR_SMAX - KMC_LR_SMIN + 1;
-            c->b_kmers = std::max<u64>(n_bases * per, 1);
-            u64 done = 0, prev = 0;
-            while (done < n_bases) {
-                u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
-                u64 take = plan(n_bases - done, per, prev);
+            // Reference mode (main.rs:63-81): every window start contributes up to 61 keys (27 + gap + 27 for
+            // sizes 80..=140), and almost every key is new (1.08 M distinct of 3.55 M on the fixture): the
+            // keys are FORMED by kmc_lr_extract_kernel and grouped by the radix sort + run-length, like the
+            // reference's own push + sort() (main.rs:79,87) -- no hash table, no per-occurrence atomics.
+            // Sub-batches of 2^25 window starts (61 x 16 B x 2 buffers = 64 GiB of keys in flight at most).
+            const u64 per = KMC_LRX_NS;
+            const u64 SB = 1ull << 25;
+            for (u64 p0 = 0; p0 < n_bases; p0 += SB) {
+                const u64 p1 = std::min(n_bases, p0 + SB);
+                const u64 n = (p1 - p0) * per;
+                for (int i = 0; i < 2; ++i) {
+                    rc = ensure(c, c->s_lo[i], (size_t)n * sizeof(u64)); if (rc) return rc;
+                    rc = ensure(c, c->s_hi[i], (size_t)n * sizeof(u64)); if (rc) return rc;
+                }
                 rc = launch_begin(c);
                 if (rc) return rc;
-                rc = kmc_lr_launch(c->stream, c->n_cu, d_bases, d_offsets, n_reads, n_bases, done, done + take, gtable_of(c, c->tab));
-                if (rc) return fail(c, rc, "LR kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+                hipLaunchKernelGGL(kmc_lr_extract_kernel, dim3((unsigned)((p1 - p0 + KMC_LRX_POS - 1) / KMC_LRX_POS)), dim3(1024), 0, c->stream,
+                                   d_bases, n_bases, d_offsets, n_reads, p0, p1, (u64*)c->s_hi[0].p, (u64*)c->s_lo[0].p, c->d_counters);
+                HIPCHK(c, hipGetLastError());
+                u64* const khi[2] = {(u64*)c->s_hi[0].p, (u64*)c->s_hi[1].p};
+                u64* const klo[2] = {(u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p};
+                u64* const kwt[2] = {nullptr, nullptr};
+                rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen);
+                if (rc) return rc;
                 rc = launch_end(c);
                 if (rc) return rc;
                 c->pending = true;
-                done += take;
-                prev = take;
-                if (done < n_bases) { rc = observe(occ, take, per); if (rc) return rc; }
             }
         }
         u64 stream_from = 0;  // base position from which the stream / sort path takes over
@@ -793,6 +985,8 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 d_vs = (const u64*)c->vr_reads.p;
                 d_ve = d_vs + n_v;
             }
+            rc = sk_ensure(c);
+            if (rc) return rc;
             if (n_v >= (1ull << 32)) return fail(c, KMC_ERR_ARG, "batch too large for one walk pass: %llu read pieces; feed smaller batches", (unsigned long long)n_v);
             {
                 void* before = c->walk_ws.p;
@@ -806,6 +1000,8 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             while (done < n_tiles) {
                 u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
                 u64 take = plan(n_tiles - done, kpt, prev);
+                if (take > plan_safe && !arm_risky(c, d_bases, d_offsets, n_reads, n_bases, 0, done ? d_ve + (done * 64 - 1) : nullptr))
+                    take = plan_safe;  // (the table cannot be saved cheaply: stay within what fits for certain)
                 if (!c->walk_ws_clean) {  // (normally the unfold kernel of the previous launch left it clean)
                     rc = kmc_walk_prepare(c->stream, c->walk_ws.p);
                     if (rc) return fail(c, rc, "walk workspace reset failed");
@@ -814,12 +1010,12 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 rc = launch_begin(c);  // the event pair brackets the walk kernel alone
                 if (rc) return rc;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
-                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), 0);
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), sk_table_of(c), 0);
                 if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
                 rc = launch_end(c);
                 if (rc) return rc;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
-                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), 1);
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), sk_table_of(c), 1);
                 if (rc) return fail(c, rc, "scalar/unfold kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
                 c->walk_ws_clean = true;
                 c->memo_parity ^= 1;
@@ -829,6 +1025,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 if (done < n_tiles) {
                     rc = observe(occ, take, kpt);
                     if (rc) return rc;
+                    if (c->recovered) break;  // (the sort path has counted the rest of the batch)
                     if (c->cfg.algo == KMC_ALGO_AUTO && c->walk_overflowed) {
                         // the memo does not help on this input (almost every k-mer is new): hand the rest
                         // of the batch to the sort path
@@ -845,12 +1042,15 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 }
             }
         }
+        if (c->recovered) { run_stream = false; run_sort = false; }
         if (run_stream) {
             const u64 n_chunks = (n_bases + KMC_CHUNK - 1) / KMC_CHUNK;
             u64 done = stream_from / KMC_CHUNK, prev = 0;
             while (done < n_chunks) {
                 u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
                 u64 take = plan(n_chunks - done, KMC_CHUNK, prev);
+                if (take > plan_safe && !arm_risky(c, d_bases, d_offsets, n_reads, n_bases, std::max<u64>(done * KMC_CHUNK, stream_from), nullptr))
+                    take = plan_safe;
                 rc = launch_stream(c, d_bases, d_offsets, n_reads, n_bases, done, done + take, stream_from);
                 if (rc) return rc;
                 c->pending = true;
@@ -859,6 +1059,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 if (done < n_chunks) {
                     rc = observe(occ, take, KMC_CHUNK);
                     if (rc) return rc;
+                    if (c->recovered) break;
                     if (is_auto && (c->rho_last > 0.2 || c->walk_overflowed)) {
                         // many new keys per k-mer, or the LDS partial tables overflow and most k-mers go to
                         // global atomics anyway: per-occurrence hashing is the wrong tool
@@ -871,6 +1072,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 }
             }
         }
+        if (c->recovered) run_sort = false;
         if (run_sort) {
             rc = run_sort_path(c, d_bases, d_offsets, n_reads, n_bases, stream_from);
             if (rc) return rc;
@@ -948,9 +1150,16 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
                       &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo, &c->vr_reads, &c->vr_cnt, &c->vr_pos,
                       &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->s_flags, &c->s_pos, &c->s_head,
-                      &c->m_hist, &c->m_stot, &c->m_rmin, &c->m_rmax, &c->m_seg[0], &c->m_seg[1], &c->m_first, &c->m_cbase, &c->m_skip, &c->m_term, &c->m_ord,
-                      &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_cnt, &c->m_w[0], &c->m_w[1]};
+                      &c->m_hist, &c->m_stot, &c->m_bsum, &c->m_rmin, &c->m_rmax, &c->m_seg[0], &c->m_seg[1], &c->m_first, &c->m_cbase, &c->m_skip, &c->m_term, &c->m_ord,
+                      &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_cnt, &c->m_w[0], &c->m_w[1],
+                      &c->snap_hi, &c->snap_lo, &c->snap_cnt, &c->snap_n, &c->snap_occ};
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    free_table(c->sk);
+    if (c->d_sk_counters) (void)hipFree(c->d_sk_counters);
+    if (c->h_sk_counters) (void)hipHostFree(c->h_sk_counters);
+    if (c->sk_spill_hi) (void)hipFree(c->sk_spill_hi);
+    if (c->sk_spill_lo) (void)hipFree(c->sk_spill_lo);
+    if (c->sk_spill_cnt) (void)hipFree(c->sk_spill_cnt);
     try { free_runs(c, true); } catch (...) { /* (only the pool bookkeeping can throw; the buffers it could not list leak with the process) */ }
     for (DevBuf* b : bufs) free_buf(*b);
     for (hipEvent_t e : c->lev) (void)hipEventDestroy(e);
@@ -1034,6 +1243,8 @@ static int kmc_reset_impl(kmc_ctx* c) {
     c->batch_pending = false;
     c->unpolled_adds = 0;
     c->b_open = false;  // (rho_hist itself is kept: it describes the data source)
+    c->risky.armed = false;
+    c->recovered = false;
     u64 cap = c->st.table_capacity;
     c->st = kmc_stats{};
     c->st.table_capacity = cap;
@@ -1143,7 +1354,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     }
     rc = poll_and_settle(c);
     if (rc) return rc;
-    const bool fast_done = tried_fast && c->h_counters[KMC_CTR_FASTFIN] == 1;
+    const bool fast_done = tried_fast && c->h_counters[KMC_CTR_FASTFIN] == 1 && c->runs.empty();  // (the poll may have recovered an overflow: runs exist now)
     const u64 n_tab = c->h_counters[KMC_CTR_OCCUPIED];
     u64 n_runs_total = 0;
     for (auto& r : c->runs) n_runs_total += r.n;
@@ -1181,12 +1392,16 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         // one sorted run and an empty table: it IS the sorted view (no copy)
         auto& r = c->runs[0];
         c->v_hi = r.hi; c->v_lo = r.lo; c->v_cnt = r.cnt;
-        HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM2], 0, sizeof(u64), c->stream));
-        hipLaunchKernelGGL(kmc_sum_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, r.cnt, n, c->d_counters);
-        HIPCHK(c, hipGetLastError());
-        rc = poll(c);
-        if (rc) return rc;
-        n_kmers = c->h_counters[KMC_CTR_SUM2];
+        if (r.total_known) {
+            n_kmers = r.total;  // (the sort already knows how many keys it counted)
+        } else {
+            HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM2], 0, sizeof(u64), c->stream));
+            hipLaunchKernelGGL(kmc_sum_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, r.cnt, n, c->d_counters);
+            HIPCHK(c, hipGetLastError());
+            rc = poll(c);
+            if (rc) return rc;
+            n_kmers = c->h_counters[KMC_CTR_SUM2];
+        }
     } else if (n) {
         if (n_tab) {
             const int parity = c->fin_parity;
@@ -1402,6 +1617,7 @@ static int kmc_forget_source_impl(kmc_ctx* c, int what) {
         HIPCHK(c, hipMemsetAsync(c->walk_memo.p, 0, kmc_walk_memo_bytes(c->n_cu, c->KW), c->stream));  // tag 0 = no snapshot
         c->memo_parity = 0;
     }
+    if (what & KMC_FORGET_MEMO) { int rs = sk_clear(c); if (rs) return rs; }
     if (what & KMC_FORGET_HISTORY) {
         c->rho_hist = -1.0;
         c->rho_last = c->rho_max = 0.0;
@@ -1647,6 +1863,13 @@ extern "C" int kmc_merge_slabs_device(kmc_ctx* c, const void* d_slabs, uint32_t 
 extern "C" int kmc_poll(kmc_ctx* c) {
     return guarded(c, [&]() -> int { return kmc_poll_impl(c); });
 }
+extern "C" int kmc_sync(kmc_ctx* c) {
+    if (!c) return KMC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return KMC_OK;
+}
+
 extern "C" int kmc_forget_source(kmc_ctx* c, int what) {
     return guarded(c, [&]() -> int { return kmc_forget_source_impl(c, what); });
 }

@@ -5,33 +5,38 @@
 //
 // The reference sorts 54-character strings one character position at a time from the END
 // (main.rs:34-40: 53 stable bucket passes over everything).  Here keys are 2 bits per base, MSB
-// first, so unsigned order = string order, and the sort goes from the FRONT, eight bits (four bases)
-// per pass, so that a key crosses HBM a few times instead of once per digit:
+// first, so unsigned order = string order, and the sort goes from the FRONT, ten bits (five bases)
+// per pass: two passes bring 2^30 keys down to buckets that fit LDS, so a key crosses HBM a few times
+// instead of once per digit:
 //
-//   level l   every ACTIVE segment (a span of the key array whose keys share their first 8*l bits) is
-//             partitioned by its next 8 bits: kmc_msd_hist_kernel counts per range of 16 Ki keys,
-//             kmc_msd_scan_kernel turns the counts into destinations and classifies the 256 children,
-//             kmc_msd_scatter_kernel moves the keys into the other buffer.  Children of at most
+//   level l   every ACTIVE segment (a span of the key array whose keys share their first 10*l bits) is
+//             partitioned by its next 10 bits: kmc_msd_hist_kernel counts per range of 16 Ki keys,
+//             kmc_msd_scan_*_kernel turn the counts into destinations and classify the 1024 children,
+//             kmc_msd_scatter_kernel moves the keys into the other buffer, tile by tile through LDS so
+//             that every child receives contiguous runs.  Children of at most
 //             KMC_MSD_LEAF keys, children whose keys are all equal and children with no bits left are
 //             TERMINAL; the rest are the next level's active segments.  Positions are shared by both
 //             buffers, so position order is key order at every level.
-//   leaves    one workgroup per terminal segment: an LDS pass on the next 8 bits, then every
-//             sub-bucket is rank-sorted inside a wave (all-pairs compare through v_readlane, no data
-//             movement), then run-length: (key, count) pairs.
+//   leaves    one workgroup per terminal segment: an LDS pass on the next 8 bits, then every thread
+//             insertion-sorts one sub-bucket (a dozen keys; larger ones are rank-sorted by a wave,
+//             all-pairs compare through v_readlane), then run-length: (key, count) pairs.
 //   output    the terminals are ordered by position with a bitmap + popcount scan, their pair counts
 //             are scanned, and the pairs are gathered into one dense sorted run.
 //
-// Invalid positions (all-ones filler from the extraction kernel) fall into a 257th bucket at level 0
+// Invalid positions (all-ones filler from the extraction kernel) fall into a 1025th bucket at level 0
 // and are dropped.  Keys may carry a 64-bit weight (an existing count): the run-length then sums
 // weights -- that is how count tables and earlier runs are merged and ordered.
 #pragma once
 #include "kmc_device.cuh"
 
 #define KMC_MSD_RANGE 16384   // keys per histogram / scatter workgroup
-#define KMC_MSD_NB 257        // digit bins: 256 + "invalid position"
+#define KMC_MSD_BITS 10       // digit width of a level (the last level of a key may be narrower)
+#define KMC_MSD_ND (1 << KMC_MSD_BITS)
+#define KMC_MSD_NB (KMC_MSD_ND + 1)   // digit bins + "invalid position"
 #define KMC_MSD_THREADS 256
 #define KMC_MSD_LEAF1 4096    // leaf capacity, one-word keys  (two LDS images of 32 KB)
 #define KMC_MSD_LEAF2 2048    // leaf capacity, two-word keys
+#define KMC_MSD_THREAD_SORT 32  // sub-buckets up to this size are insertion-sorted by one thread
 
 struct MsdSeg { u32 begin, len; };
 // kind 0: leaf (sort in LDS); kind 1: all keys equal (one pair, key = first element)
@@ -45,7 +50,8 @@ struct MsdCtl {
     u32 n_ranges;    // ranges of the current level (written by kmc_msd_ranges_kernel)
     u32 overflow;    // a list ran out of room (host checks)
     u32 n_pairs;     // total (key, count) pairs (written by the terminal scan)
-    u32 pad[2];
+    u32 scan_total;  // total of the last kmc_scan_* call
+    u32 pad;
 };
 
 template <int KW>
@@ -53,7 +59,7 @@ __device__ __forceinline__ bool msd_is_filler(u64 hi, u64 lo, int kb) {
     if (KW == 1) return kb < 64 && (lo >> kb) != 0;
     return (hi >> (kb - 64)) != 0;  // kb in [64, 126]
 }
-// bits [shift, shift + 8) of the key (the caller masks the last, narrower level)
+// bits [shift, shift + 32) of the key (the caller masks)
 template <int KW>
 __device__ __forceinline__ u32 msd_bits(u64 hi, u64 lo, int shift) {
     if (KW == 1) return (u32)(lo >> shift);
@@ -62,13 +68,75 @@ __device__ __forceinline__ u32 msd_bits(u64 hi, u64 lo, int shift) {
     return (u32)((lo >> shift) | (hi << (64 - shift)));
 }
 
+// ---- exclusive scan of a u32 sequence, three small kernels (block sums, scan of the sums, final) ----
+// MODE 0: the values themselves; MODE 1: popcount of 64-bit words (bitmap rank)
+#define KMC_SCAN_PER_BLOCK 2048
+template <int MODE>
+__device__ __forceinline__ u32 scan_value(const void* src, u32 i) {
+    if (MODE == 0) return reinterpret_cast<const u32*>(src)[i];
+    return (u32)__popcll(reinterpret_cast<const unsigned long long*>(src)[i]);
+}
+template <int MODE>
+__global__ __launch_bounds__(256)
+void kmc_scan_sums_kernel(const void* __restrict__ src, u32 n, u32* __restrict__ bsum) {
+    __shared__ u32 ws[4];
+    const u32 tid = threadIdx.x, i0 = blockIdx.x * KMC_SCAN_PER_BLOCK + tid * 8;
+    u32 s = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) if (i0 + e < n) s += scan_value<MODE>(src, i0 + e);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((tid & 63) == 0) ws[tid >> 6] = s;
+    __syncthreads();
+    if (tid == 0) bsum[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+// in-place exclusive scan of up to a few hundred thousand block sums; total -> *total (one workgroup)
+__global__ __launch_bounds__(1024)
+void kmc_scan_top_kernel(u32* __restrict__ bsum, u32 nb, u32* __restrict__ total) {
+    __shared__ u32 part[1024];
+    const u32 tid = threadIdx.x;
+    const u32 per = (nb + 1023) / 1024;
+    const u32 a = min(tid * per, nb), b = min(a + per, nb);
+    u32 s = 0;
+    for (u32 i = a; i < b; ++i) s += bsum[i];
+    part[tid] = s;
+    __syncthreads();
+    for (u32 o = 1; o < 1024; o <<= 1) {
+        u32 v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    u32 run = tid ? part[tid - 1] : 0;
+    for (u32 i = a; i < b; ++i) { const u32 v = bsum[i]; bsum[i] = run; run += v; }
+    if (tid == 1023) *total = part[1023];
+}
+template <int MODE>
+__global__ __launch_bounds__(256)
+void kmc_scan_final_kernel(const void* __restrict__ src, u32 n, const u32* __restrict__ bbase, u32* __restrict__ out) {
+    __shared__ u32 ws[4];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, i0 = blockIdx.x * KMC_SCAN_PER_BLOCK + tid * 8;
+    u32 v[8], s = 0;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = (i0 + e < n) ? scan_value<MODE>(src, i0 + e) : 0u; s += v[e]; }
+    u32 inc = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 t = __shfl_up(inc, o); if ((int)lane >= o) inc += t; }
+    if (lane == 63) ws[wv] = inc;
+    __syncthreads();
+    u32 run = bbase[blockIdx.x] + inc - s;
+    for (u32 w = 0; w < wv; ++w) run += ws[w];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { if (i0 + e < n) out[i0 + e] = run; run += v[e]; }
+}
+
 // first[i] = number of ranges of segments 0..i-1; ctl->n_ranges = total.  One workgroup.
 __global__ __launch_bounds__(1024)
 void kmc_msd_ranges_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, u32* __restrict__ first, MsdCtl* ctl) {
     __shared__ u32 part[1024];
     const u32 tid = threadIdx.x;
     const u32 per = (n_seg + 1023) / 1024;
-    const u32 a = tid * per, b = min(a + per, n_seg);
+    const u32 a = min(tid * per, n_seg), b = min(a + per, n_seg);
     u32 s = 0;
     for (u32 i = a; i < b; ++i) s += (seg[i].len + KMC_MSD_RANGE - 1) / KMC_MSD_RANGE;
     part[tid] = s;
@@ -94,7 +162,7 @@ __device__ __forceinline__ u32 msd_seg_of(const u32* __restrict__ first, u32 n_s
     return lo;
 }
 
-// per range: digit histogram (hist[r][257]) and min / max key (all-equal segments end here)
+// per range: digit histogram (hist[r][NB]) and min / max key (all-equal segments end here)
 template <int KW>
 __global__ __launch_bounds__(KMC_MSD_THREADS)
 void kmc_msd_hist_kernel(const u64* __restrict__ khi, const u64* __restrict__ klo, const MsdSeg* __restrict__ seg, u32 n_seg,
@@ -114,7 +182,7 @@ void kmc_msd_hist_kernel(const u64* __restrict__ khi, const u64* __restrict__ kl
     for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
         const u64 lo = klo[b + i], hi = KW == 2 ? khi[b + i] : 0ull;
         u32 d;
-        if (level0 && msd_is_filler<KW>(hi, lo, kb)) d = 256;
+        if (level0 && msd_is_filler<KW>(hi, lo, kb)) d = KMC_MSD_ND;
         else {
             d = msd_bits<KW>(hi, lo, shift) & mask;
             if (key_less(hi, lo, mnh, mnl)) { mnh = hi; mnl = lo; }
@@ -122,7 +190,6 @@ void kmc_msd_hist_kernel(const u64* __restrict__ khi, const u64* __restrict__ kl
         }
         atomicAdd(&h[wv][d], 1u);
     }
-    // wave min / max
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const u64 oh = __shfl_xor(mnh, o), ol = __shfl_xor(mnl, o);
@@ -144,10 +211,10 @@ void kmc_msd_hist_kernel(const u64* __restrict__ khi, const u64* __restrict__ kl
 }
 
 // Scan, part A: for every (segment, digit) the exclusive running offsets over the segment's ranges (in
-// place in hist) and the digit's total (stot[s][257]).  One WAVE scans one digit's column 64 ranges at a
+// place in hist) and the digit's total (stot[s][NB]).  One WAVE scans one digit's column 64 ranges at a
 // time; the grid is n_seg x S workgroups of four waves, wave w of workgroup j of a segment takes the
-// digits j*4 + w + 4*S*i.  (S = 65: one digit per wave -- level 0 is ONE segment of tens of thousands
-// of ranges, which a single workgroup would walk for milliseconds; S = 1 when there are many segments.)
+// digits j*4 + w + 4*S*i.  (Level 0 is ONE segment of tens of thousands of ranges, which a single
+// workgroup would walk for milliseconds: S = 64 there; S = 1 when there are many segments.)
 __global__ __launch_bounds__(KMC_MSD_THREADS)
 void kmc_msd_scan_a_kernel(u32 n_seg, u32 S, const u32* __restrict__ first, u32* __restrict__ hist, u32* __restrict__ stot) {
     const u32 s = blockIdx.x / S, j = blockIdx.x % S, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -169,25 +236,27 @@ void kmc_msd_scan_a_kernel(u32 n_seg, u32 S, const u32* __restrict__ first, u32*
     }
 }
 
-// Scan, part B: one workgroup per active segment: child destinations (cbase[s][257]) from the digit
-// totals, and the classification of the children.
+// Scan, part B: one workgroup (one thread per digit) per active segment: child destinations
+// (cbase[s][NB]) from the digit totals, and the classification of the children.
 //   seg_skip[s] = 1: every key of the segment is equal -- it becomes a terminal as it stands (in the
 //   SOURCE buffer) and its ranges are not scattered.
-__global__ __launch_bounds__(KMC_MSD_THREADS)
+__global__ __launch_bounds__(KMC_MSD_ND)
 void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* __restrict__ first, const u32* __restrict__ stot,
                          const u64* __restrict__ rmin, const u64* __restrict__ rmax, u32* __restrict__ cbase, u32* __restrict__ seg_skip,
                          int last_level, int level0, u32 leaf_cap, u32 src_parity,
                          MsdSeg* __restrict__ next, u32 next_cap, MsdTerm* __restrict__ term, u32 term_cap,
                          unsigned long long* __restrict__ bitmap, MsdCtl* ctl) {
+    constexpr int NWV = KMC_MSD_ND / 64;
     __shared__ u32 tot[KMC_MSD_NB + 7];
-    __shared__ u32 wsum[4];
-    __shared__ u64 smm[4][4];
-    const u32 s = blockIdx.x, tid = threadIdx.x;
+    __shared__ u32 cb_s[KMC_MSD_ND];
+    __shared__ u32 wsum[NWV];
+    __shared__ u64 smm[NWV][4];
+    const u32 s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 r0 = first[s], r1 = first[s + 1];
     // are all keys of the segment equal?  (fold the ranges' min / max)
     {
         u64 mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
-        for (u32 r = r0 + tid; r < r1; r += KMC_MSD_THREADS) {
+        for (u32 r = r0 + tid; r < r1; r += KMC_MSD_ND) {
             const u64 ah = rmin[2 * (size_t)r], al = rmin[2 * (size_t)r + 1], bh = rmax[2 * (size_t)r], bl = rmax[2 * (size_t)r + 1];
             if (key_less(ah, al, mnh, mnl)) { mnh = ah; mnl = al; }
             if (key_less(mxh, mxl, bh, bl)) { mxh = bh; mxl = bl; }
@@ -199,37 +268,36 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
             const u64 ph = __shfl_xor(mxh, o), pl = __shfl_xor(mxl, o);
             if (key_less(mxh, mxl, ph, pl)) { mxh = ph; mxl = pl; }
         }
-        if ((tid & 63) == 0) { smm[tid >> 6][0] = mnh; smm[tid >> 6][1] = mnl; smm[tid >> 6][2] = mxh; smm[tid >> 6][3] = mxl; }
+        if (lane == 0) { smm[wv][0] = mnh; smm[wv][1] = mnl; smm[wv][2] = mxh; smm[wv][3] = mxl; }
     }
-    for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_THREADS) tot[d] = stot[(size_t)s * KMC_MSD_NB + d];
+    for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_ND) tot[d] = stot[(size_t)s * KMC_MSD_NB + d];
     __syncthreads();
     bool all_equal;
     {
         u64 mnh = smm[0][0], mnl = smm[0][1], mxh = smm[0][2], mxl = smm[0][3];
-        for (int w = 1; w < 4; ++w) {
+        for (int w = 1; w < NWV; ++w) {
             if (key_less(smm[w][0], smm[w][1], mnh, mnl)) { mnh = smm[w][0]; mnl = smm[w][1]; }
             if (key_less(mxh, mxl, smm[w][2], smm[w][3])) { mxh = smm[w][2]; mxl = smm[w][3]; }
         }
         all_equal = mnh == mxh && mnl == mxl;
     }
-    const u32 n_filler = level0 ? tot[256] : 0;
+    const u32 n_filler = level0 ? tot[KMC_MSD_ND] : 0;
     const bool equal = all_equal && seg[s].len > n_filler && (!level0 || n_filler == 0);
-    // exclusive scan of tot[0..255] -> child begin (the filler bucket is dropped)
+    // exclusive scan of tot[0..ND) -> child begin (the filler bucket is dropped)
     const u32 mine = tot[tid];
     u32 inc = mine;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if ((int)(tid & 63) >= o) inc += v; }
-    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
     u32 wbase = 0;
-    for (u32 w = 0; w < (tid >> 6); ++w) wbase += wsum[w];
+    for (u32 w = 0; w < wv; ++w) wbase += wsum[w];
     const u32 cb = seg[s].begin + wbase + inc - mine;
     cbase[(size_t)s * KMC_MSD_NB + tid] = cb;
-    __shared__ u32 cb_s[256];
     cb_s[tid] = cb;
     __syncthreads();
     if (tid != 0) return;
-    cbase[(size_t)s * KMC_MSD_NB + 256] = 0;
+    cbase[(size_t)s * KMC_MSD_NB + KMC_MSD_ND] = 0;
     seg_skip[s] = equal ? 1u : 0u;
     if (level0) ctl->n_valid = seg[s].len - n_filler;
     auto emit_term = [&](u32 b, u32 l, u32 kind, u32 parity) {
@@ -247,7 +315,7 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
     // pair each); runs of consecutive small ones are merged into leaves of at most leaf_cap keys (a
     // leaf sorts whatever keys it holds, so it need not be a single child)
     u32 gb = 0, gl = 0;
-    for (u32 d = 0; d < 256; ++d) {
+    for (u32 d = 0; d < KMC_MSD_ND; ++d) {
         const u32 m = tot[d];
         if (!m) continue;
         if (m > leaf_cap) {
@@ -266,57 +334,108 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
     if (gl) emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u);
 }
 
-// per range: move every key (and weight) to its child's span in the other buffer
+// Per range: move every key (and weight) to its child's span in the other buffer.  A tile of keys is
+// grouped by digit in LDS first (rank within the tile from one returning LDS add per key), then
+// written out in that order: consecutive lanes write consecutive addresses of one child, so a child
+// receives a contiguous run per tile instead of single 8-byte stores (the first version scattered
+// straight from registers: 1.4 TB/s).
+template <int KW, bool WEIGHTS> struct MsdScatterLds {
+    static constexpr int WORDS = KW + (WEIGHTS ? 1 : 0);
+    static constexpr int TILE = WORDS == 1 ? 8192 : (WORDS == 2 ? 4096 : 2048);
+    u64 lo[TILE];
+    u64 hi[KW == 2 ? TILE : 1];
+    u64 w[WEIGHTS ? TILE : 1];
+    u32 cnt[KMC_MSD_NB + 3];   // keys of the tile per digit, then their exclusive prefix
+    u32 gdst[KMC_MSD_NB + 3];  // global index of the tile's first key of the digit, minus its LDS index
+    u32 cur[KMC_MSD_NB + 3];   // the range's running destination per digit
+    u32 wsum[16];
+};
 template <int KW, bool WEIGHTS>
-__global__ __launch_bounds__(KMC_MSD_THREADS)
+__global__ __launch_bounds__(1024)
 void kmc_msd_scatter_kernel(const u64* __restrict__ khi, const u64* __restrict__ klo, const u64* __restrict__ kw,
                             u64* __restrict__ ohi, u64* __restrict__ olo, u64* __restrict__ ow,
                             const MsdSeg* __restrict__ seg, u32 n_seg, const u32* __restrict__ first,
                             const u32* __restrict__ hist, const u32* __restrict__ cbase, const u32* __restrict__ seg_skip,
                             int shift, u32 mask, int kb, int level0, const MsdCtl* __restrict__ ctl) {
-    __shared__ u32 cur[KMC_MSD_NB + 3];
-    const u32 r = blockIdx.x, tid = threadIdx.x;
+    extern __shared__ __align__(16) unsigned char msd_smem[];
+    typedef MsdScatterLds<KW, WEIGHTS> LT;
+    LT& L = *reinterpret_cast<LT*>(msd_smem);
+    constexpr int TILE = LT::TILE, PER = TILE / 1024;
+    const u32 r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (r >= ctl->n_ranges) return;
     const u32 s = msd_seg_of(first, n_seg, r);
     if (seg_skip[s]) return;  // (block-uniform)
-    for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_THREADS) cur[d] = cbase[(size_t)s * KMC_MSD_NB + d] + hist[(size_t)r * KMC_MSD_NB + d];
-    __syncthreads();
+    for (u32 d = tid; d < KMC_MSD_NB; d += 1024) L.cur[d] = cbase[(size_t)s * KMC_MSD_NB + d] + hist[(size_t)r * KMC_MSD_NB + d];
     const u32 idx = r - first[s];
     const u32 b = seg[s].begin + idx * KMC_MSD_RANGE;
     const u32 n = min((u32)KMC_MSD_RANGE, seg[s].len - idx * KMC_MSD_RANGE);
-    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
-        const u64 lo = klo[b + i], hi = KW == 2 ? khi[b + i] : 0ull;
-        if (level0 && msd_is_filler<KW>(hi, lo, kb)) continue;
-        const u32 d = msd_bits<KW>(hi, lo, shift) & mask;
-        const u32 p = atomicAdd(&cur[d], 1u);
-        olo[p] = lo;
-        if (KW == 2) ohi[p] = hi;
-        if (WEIGHTS) ow[p] = kw[b + i];
+    for (u32 t0 = 0; t0 < n; t0 += TILE) {
+        const u32 tn = min((u32)TILE, n - t0);
+        for (u32 d = tid; d < KMC_MSD_NB; d += 1024) L.cnt[d] = 0;
+        __syncthreads();
+        // 1. my keys, their digits and their ranks within the tile
+        u64 mlo[PER], mhi[PER], mw[PER];
+        u32 md[PER], mr[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const u32 i = t0 + tid + 1024u * e;
+            md[e] = ~0u;
+            if (tid + 1024u * e < tn) {
+                mlo[e] = klo[b + i];
+                mhi[e] = KW == 2 ? khi[b + i] : 0ull;
+                if (WEIGHTS) mw[e] = kw[b + i];
+                md[e] = (level0 && msd_is_filler<KW>(mhi[e], mlo[e], kb)) ? (u32)KMC_MSD_ND : (msd_bits<KW>(mhi[e], mlo[e], shift) & mask);
+                mr[e] = atomicAdd(&L.cnt[md[e]], 1u);
+            }
+        }
+        __syncthreads();
+        // 2. exclusive prefix of the tile's digit counts (thread d <-> digit d; the filler bin comes last)
+        {
+            const u32 c = L.cnt[tid];
+            u32 inc = c;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+            if (lane == 63) L.wsum[wv] = inc;
+            __syncthreads();
+            u32 base = 0;
+            for (u32 w = 0; w < wv; ++w) base += L.wsum[w];
+            const u32 off = base + inc - c;
+            L.cnt[tid] = off;
+            L.gdst[tid] = L.cur[tid] - off;
+            L.cur[tid] += c;
+            if (tid == 1023) L.cnt[KMC_MSD_ND] = off + c;  // fillers sit behind every key and are not written out
+        }
+        __syncthreads();
+        // 3. into LDS, grouped by digit
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            if (md[e] != ~0u) {
+                const u32 p = L.cnt[md[e]] + mr[e];
+                L.lo[p] = mlo[e];
+                if (KW == 2) L.hi[p] = mhi[e];
+                if (WEIGHTS) L.w[p] = mw[e];
+            }
+        }
+        __syncthreads();
+        // 4. out, in LDS order
+        const u32 n_keys = L.cnt[KMC_MSD_ND];  // keys of the tile that are not filler
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const u32 p = tid + 1024u * e;
+            if (p < n_keys) {
+                const u64 lo = L.lo[p], hi = KW == 2 ? L.hi[p] : 0ull;
+                const u32 d = msd_bits<KW>(hi, lo, shift) & mask;
+                const u32 q = L.gdst[d] + p;
+                olo[q] = lo;
+                if (KW == 2) ohi[q] = hi;
+                if (WEIGHTS) ow[q] = L.w[p];
+            }
+        }
+        __syncthreads();
     }
 }
 
-// ---- terminals in position order ---------------------------------------------------------------
-// rank[w] = number of set bits in bitmap words 0..w-1 (one workgroup; the bitmap has one bit per key)
-__global__ __launch_bounds__(1024)
-void kmc_msd_bitrank_kernel(const unsigned long long* __restrict__ bitmap, u32 n_words, u32* __restrict__ rank) {
-    __shared__ u32 part[1024];
-    const u32 tid = threadIdx.x;
-    const u32 per = (n_words + 1023) / 1024;
-    const u32 a = tid * per, b = min(a + per, n_words);
-    u32 s = 0;
-    for (u32 i = a; i < b; ++i) s += (u32)__popcll(bitmap[i]);
-    part[tid] = s;
-    __syncthreads();
-    for (u32 o = 1; o < 1024; o <<= 1) {
-        u32 v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    u32 run = tid ? part[tid - 1] : 0;
-    for (u32 i = a; i < b; ++i) { rank[i] = run; run += (u32)__popcll(bitmap[i]); }
-}
-// ordered[t] = the terminal whose begin has ordinal t
+// ordered[t] = the terminal whose begin has ordinal t (rank = exclusive popcount prefix of the bitmap words)
 __global__ void kmc_msd_order_kernel(const MsdTerm* __restrict__ term, u32 n_term, const unsigned long long* __restrict__ bitmap,
                                      const u32* __restrict__ rank, MsdTerm* __restrict__ ordered) {
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_term; i += gridDim.x * blockDim.x) {
@@ -325,58 +444,22 @@ __global__ void kmc_msd_order_kernel(const MsdTerm* __restrict__ term, u32 n_ter
         ordered[rank[p >> 6] + (u32)__popcll(below)] = term[i];
     }
 }
-// exclusive scan of nd[0..n) -> base[0..n), total -> ctl->n_pairs (one workgroup)
-__global__ __launch_bounds__(1024)
-void kmc_msd_scan_nd_kernel(const u32* __restrict__ nd, u32 n, u32* __restrict__ base, MsdCtl* ctl) {
-    __shared__ u32 part[1024];
-    const u32 tid = threadIdx.x;
-    const u32 per = (n + 1023) / 1024;
-    const u32 a = tid * per, b = min(a + per, n);
-    u32 s = 0;
-    for (u32 i = a; i < b; ++i) s += nd[i];
-    part[tid] = s;
-    __syncthreads();
-    for (u32 o = 1; o < 1024; o <<= 1) {
-        u32 v = tid >= o ? part[tid - o] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
-    }
-    u32 run = tid ? part[tid - 1] : 0;
-    for (u32 i = a; i < b; ++i) { base[i] = run; run += nd[i]; }
-    if (tid == 1023) ctl->n_pairs = part[1023];
-}
 
 // ---- leaves ------------------------------------------------------------------------------------
 // One workgroup per terminal (in position order).  Result: the terminal's (key, count) pairs, sorted,
-// written IN PLACE at the terminal's span of the pair staging arrays (t_hi/t_lo/t_cnt; at most len
-// pairs), and nd[t] = their number.  kmc_msd_gather_kernel then makes the run dense.
+// written at the terminal's own positions of the OTHER key buffer (dead there) and of t_cnt, and
+// nd[t] = their number.  kmc_msd_gather_kernel then makes the run dense.
 template <int KW, bool WEIGHTS> struct MsdLeafLds {
     static constexpr int CAP = KW == 1 ? KMC_MSD_LEAF1 : KMC_MSD_LEAF2;
     u64 a_lo[CAP], b_lo[CAP];
     u64 a_hi[KW == 2 ? CAP : 1], b_hi[KW == 2 ? CAP : 1];
-    u64 a_w[WEIGHTS ? CAP : 1], b_w[CAP];   // weights (counts) of the keys; b_w also receives the run sums
+    u64 a_w[WEIGHTS ? CAP : 1], b_w[WEIGHTS ? CAP : 1];   // weights (counts) of the keys
     u32 cnt[256], off[257];
     u32 wsum[4];
     u32 bad;                  // a sub-bucket was too large for the in-wave rank sort
     u32 n_out;
+    u64 sx[4][2], sy[4][2];
 };
-
-// in-wave rank sort of m <= 64 keys held one per lane (lanes >= m idle): returns the sorted position
-// of this lane's key; equal keys keep their lane order
-template <int KW>
-__device__ __forceinline__ u32 msd_wave_rank(u64 hi, u64 lo, u32 m, u32 lane) {
-    u32 rank = 0;
-    for (u32 j = 0; j < m; ++j) {
-        const u64 ol = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(lo >> 32), (int)j) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)lo, (int)j);
-        u64 oh = 0;
-        if (KW == 2) oh = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(hi >> 32), (int)j) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)hi, (int)j);
-        const bool less = key_less(oh, ol, hi, lo);
-        const bool eq = oh == hi && ol == lo;
-        rank += (less || (eq && j < lane)) ? 1u : 0u;
-    }
-    return rank;
-}
 
 template <int KW, bool WEIGHTS>
 __global__ __launch_bounds__(KMC_MSD_THREADS)
@@ -387,7 +470,6 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
                          u64* __restrict__ t_cnt, u32* __restrict__ nd) {
     extern __shared__ __align__(16) unsigned char msd_smem[];
     MsdLeafLds<KW, WEIGHTS>& L = *reinterpret_cast<MsdLeafLds<KW, WEIGHTS>*>(msd_smem);
-    constexpr int CAP = MsdLeafLds<KW, WEIGHTS>::CAP;
     const u32 t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const MsdTerm T = term[t];
     const u64* khi = T.parity ? hi1 : hi0;
@@ -396,62 +478,80 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     // pair staging: the OTHER buffer at the terminal's own positions (dead there: an ancestor's keys)
     u64* const t_lo = T.parity ? s_lo0 : s_lo1;
     u64* const t_hi = T.parity ? s_hi0 : s_hi1;
+    const u32 n = T.len;
     if (T.kind == 1) {  // all keys equal: one pair
-        if (!WEIGHTS) {
-            if (tid == 0) { t_lo[T.begin] = klo[T.begin]; if (KW == 2) t_hi[T.begin] = khi[T.begin]; t_cnt[T.begin] = T.len; nd[t] = 1; }
-        } else {
-            u64 s = 0;
-            for (u32 i = tid; i < T.len; i += KMC_MSD_THREADS) s += kw[T.begin + i];
+        u64 s = n;
+        if (WEIGHTS) {
+            s = 0;
+            for (u32 i = tid; i < n; i += KMC_MSD_THREADS) s += kw[T.begin + i];
             s = wave_sum_u64(s);
-            __shared__ u64 ws[4];
-            if (lane == 0) ws[wv] = s;
+            if (lane == 0) L.sx[wv][0] = s;
             __syncthreads();
-            if (tid == 0) { t_lo[T.begin] = klo[T.begin]; if (KW == 2) t_hi[T.begin] = khi[T.begin]; t_cnt[T.begin] = ws[0] + ws[1] + ws[2] + ws[3]; nd[t] = 1; }
+            s = L.sx[0][0] + L.sx[1][0] + L.sx[2][0] + L.sx[3][0];
         }
+        if (tid == 0) { t_lo[T.begin] = klo[T.begin]; if (KW == 2) t_hi[T.begin] = khi[T.begin]; t_cnt[T.begin] = s; nd[t] = 1; }
         return;
     }
-    const u32 n = T.len;  // <= CAP
-    // 1. load; the sub-bucket digit = the 8 bits below the prefix the keys of a leaf may still differ
-    //    in.  That prefix is not recorded, so take the highest bit in which any two keys differ.
-    u64 xh = 0, xl = 0;
-    u64 fh = 0, fl = 0;
-    if (n) { fl = klo[T.begin]; if (KW == 2) fh = khi[T.begin]; }
+    // 1. load (n <= CAP) and find the smallest and the largest key.  Sub-bucket of a key = (key - min) >> sh,
+    //    sh chosen so that max lands in bucket 255 at most: order-preserving, and even over the leaf's
+    //    actual key range.  (A leaf may hold several children of its parent; the first version took the 8
+    //    bits below the highest DIFFERING bit -- for a leaf that straddles a power of two, e.g. children
+    //    0111111111 and 1000000000, that put all keys into two sub-buckets: 65 of the sort's 97 ms.)
+    u64 mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
     for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
         const u64 lo = klo[T.begin + i], hi = KW == 2 ? khi[T.begin + i] : 0ull;
         L.a_lo[i] = lo;
         if (KW == 2) L.a_hi[i] = hi;
         if (WEIGHTS) L.a_w[i] = kw[T.begin + i];
-        xl |= lo ^ fl;
-        xh |= hi ^ fh;
+        if (key_less(hi, lo, mnh, mnl)) { mnh = hi; mnl = lo; }
+        if (key_less(mxh, mxl, hi, lo)) { mxh = hi; mxl = lo; }
     }
-    if (tid < 256) L.cnt[tid] = 0;
+    L.cnt[tid] = 0;
     if (tid == 0) { L.bad = 0; L.n_out = 0; }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { xl |= __shfl_xor(xl, o); xh |= __shfl_xor(xh, o); }
-    __shared__ u64 sx[4][2];
-    if (lane == 0) { sx[wv][0] = xh; sx[wv][1] = xl; }
+    for (int o = 32; o > 0; o >>= 1) {
+        const u64 oh = __shfl_xor(mnh, o), ol = __shfl_xor(mnl, o);
+        if (key_less(oh, ol, mnh, mnl)) { mnh = oh; mnl = ol; }
+        const u64 ph = __shfl_xor(mxh, o), pl = __shfl_xor(mxl, o);
+        if (key_less(mxh, mxl, ph, pl)) { mxh = ph; mxl = pl; }
+    }
+    if (lane == 0) { L.sx[wv][0] = mnh; L.sx[wv][1] = mnl; L.sy[wv][0] = mxh; L.sy[wv][1] = mxl; }
     __syncthreads();
-    xh = sx[0][0] | sx[1][0] | sx[2][0] | sx[3][0];
-    xl = sx[0][1] | sx[1][1] | sx[2][1] | sx[3][1];
-    int top = -1;  // highest differing bit
-    if (KW == 2 && xh) top = 127 - __clzll((long long)xh);
-    else if (xl) top = 63 - __clzll((long long)xl);
+    mnh = L.sx[0][0]; mnl = L.sx[0][1]; mxh = L.sy[0][0]; mxl = L.sy[0][1];
+    for (int w = 1; w < 4; ++w) {
+        if (key_less(L.sx[w][0], L.sx[w][1], mnh, mnl)) { mnh = L.sx[w][0]; mnl = L.sx[w][1]; }
+        if (key_less(mxh, mxl, L.sy[w][0], L.sy[w][1])) { mxh = L.sy[w][0]; mxl = L.sy[w][1]; }
+    }
+    const u64 fh = mnh, fl = mnl;
+    // range = max - min (128 bits)
+    const u64 rl = mxl - mnl, rh = mxh - mnh - (mxl < mnl ? 1ull : 0ull);
+    const int top = rh ? 127 - __clzll((long long)rh) : (rl ? 63 - __clzll((long long)rl) : -1);
     if (top < 0) {  // every key of the leaf is the same: one pair
-        u64 sw = 0;
+        u64 sw = n;
         if (WEIGHTS) {
+            __syncthreads();
+            sw = 0;
             for (u32 i = tid; i < n; i += KMC_MSD_THREADS) sw += L.a_w[i];
             sw = wave_sum_u64(sw);
-            if (lane == 0) sx[wv][0] = sw;
+            if (lane == 0) L.sx[wv][0] = sw;
             __syncthreads();
-            sw = sx[0][0] + sx[1][0] + sx[2][0] + sx[3][0];
-        } else sw = n;
+            sw = L.sx[0][0] + L.sx[1][0] + L.sx[2][0] + L.sx[3][0];
+        }
         if (tid == 0) { t_lo[T.begin] = fl; if (KW == 2) t_hi[T.begin] = fh; t_cnt[T.begin] = sw; nd[t] = n ? 1u : 0u; }
         return;
     }
-    int shift = top - 7;
-    if (shift < 0) shift = 0;
+    const int shift = top >= 8 ? top - 7 : 0;
+    // sub-bucket of a key: ((key - min) >> shift), at most 255
+    auto bucket = [&](u64 hi, u64 lo) -> u32 {
+        const u64 dl = lo - mnl;
+        if (KW == 1) return (u32)(dl >> shift);
+        const u64 dh = hi - mnh - (lo < mnl ? 1ull : 0ull);
+        if (shift >= 64) return (u32)(dh >> (shift - 64));
+        if (shift == 0) return (u32)dl;
+        return (u32)((dl >> shift) | (dh << (64 - shift)));
+    };
     // 2. LDS pass: a -> b grouped by digit
-    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) atomicAdd(&L.cnt[msd_bits<KW>(KW == 2 ? L.a_hi[i] : 0ull, L.a_lo[i], shift) & 255u], 1u);
+    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) atomicAdd(&L.cnt[bucket(KW == 2 ? L.a_hi[i] : 0ull, L.a_lo[i]) & 255u], 1u);
     __syncthreads();
     {
         const u32 mine = L.cnt[tid];
@@ -470,54 +570,78 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     }
     for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
         const u64 lo = L.a_lo[i], hi = KW == 2 ? L.a_hi[i] : 0ull;
-        const u32 p = atomicAdd(&L.cnt[msd_bits<KW>(hi, lo, shift) & 255u], 1u);
+        const u32 p = atomicAdd(&L.cnt[bucket(hi, lo) & 255u], 1u);
         L.b_lo[p] = lo;
         if (KW == 2) L.b_hi[p] = hi;
         if (WEIGHTS) L.b_w[p] = L.a_w[i];
     }
     __syncthreads();
-    // 3. every sub-bucket: rank sort inside a wave, b -> a (sub-buckets of more than 64 keys in
-    //    rounds: the keys of the bucket that are smaller are counted 64 at a time)
+    // 3a. thread d insertion-sorts sub-bucket d in place (a dozen keys on average)
+    {
+        const u32 o = L.off[tid], m = L.off[tid + 1] - o;
+        if (m > 1 && m <= KMC_MSD_THREAD_SORT) {
+            for (u32 i = 1; i < m; ++i) {
+                const u64 lo = L.b_lo[o + i], hi = KW == 2 ? L.b_hi[o + i] : 0ull;
+                u64 w = 0;
+                if (WEIGHTS) w = L.b_w[o + i];
+                u32 j = i;
+                while (j > 0) {
+                    const u64 pl = L.b_lo[o + j - 1], ph = KW == 2 ? L.b_hi[o + j - 1] : 0ull;
+                    if (!key_less(hi, lo, ph, pl)) break;
+                    L.b_lo[o + j] = pl;
+                    if (KW == 2) L.b_hi[o + j] = ph;
+                    if (WEIGHTS) L.b_w[o + j] = L.b_w[o + j - 1];
+                    --j;
+                }
+                if (j != i) {
+                    L.b_lo[o + j] = lo;
+                    if (KW == 2) L.b_hi[o + j] = hi;
+                    if (WEIGHTS) L.b_w[o + j] = w;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // 3b. larger sub-buckets: rank sort by a wave (all-pairs, 64 keys of the bucket at a time), b -> a -> b
     for (u32 d = wv; d < 256; d += 4) {
         const u32 o = L.off[d], m = L.off[d + 1] - o;
-        if (m == 0) continue;
-        if (m <= 64) {
+        if (m <= KMC_MSD_THREAD_SORT) continue;
+        if (m > 1024) { if (lane == 0) L.bad = 1; continue; }
+        for (u32 c = 0; c < m; c += 64) {          // the chunk whose keys get their positions
+            const u32 i = c + lane;
             u64 lo = 0, hi = 0, w = 0;
-            if (lane < m) { lo = L.b_lo[o + lane]; if (KW == 2) hi = L.b_hi[o + lane]; if (WEIGHTS) w = L.b_w[o + lane]; }
-            const u32 rk = msd_wave_rank<KW>(hi, lo, m, lane);
-            if (lane < m) { L.a_lo[o + rk] = lo; if (KW == 2) L.a_hi[o + rk] = hi; if (WEIGHTS) L.a_w[o + rk] = w; }
-        } else if (m <= 1024) {
-            // all-pairs in rounds: my key(s) against every block of 64 keys of the bucket
-            for (u32 c = 0; c < m; c += 64) {          // the chunk whose keys get their positions
-                const u32 i = c + lane;
-                u64 lo = 0, hi = 0, w = 0;
-                const bool have = i < m;
-                if (have) { lo = L.b_lo[o + i]; if (KW == 2) hi = L.b_hi[o + i]; if (WEIGHTS) w = L.b_w[o + i]; }
-                u32 rk = 0;
-                for (u32 e = 0; e < m; e += 64) {      // against chunk e
-                    const u32 j = e + lane;
-                    u64 ql = ~0ull, qh = ~0ull;
-                    if (j < m) { ql = L.b_lo[o + j]; qh = KW == 2 ? L.b_hi[o + j] : 0ull; }
-                    const u32 mm = min(64u, m - e);
-                    for (u32 x = 0; x < mm; ++x) {
-                        const u64 ol = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(ql >> 32), (int)x) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)ql, (int)x);
-                        u64 oh = 0;
-                        if (KW == 2) oh = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(qh >> 32), (int)x) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)qh, (int)x);
-                        const bool less = key_less(oh, ol, hi, lo);
-                        const bool eq = oh == hi && ol == lo;
-                        rk += (less || (eq && (e + x) < i)) ? 1u : 0u;
-                    }
+            const bool have = i < m;
+            if (have) { lo = L.b_lo[o + i]; if (KW == 2) hi = L.b_hi[o + i]; if (WEIGHTS) w = L.b_w[o + i]; }
+            u32 rk = 0;
+            for (u32 e = 0; e < m; e += 64) {      // against chunk e
+                const u32 j = e + lane;
+                u64 ql = ~0ull, qh = ~0ull;
+                if (j < m) { ql = L.b_lo[o + j]; qh = KW == 2 ? L.b_hi[o + j] : 0ull; }
+                const u32 mm = min(64u, m - e);
+                for (u32 x = 0; x < mm; ++x) {
+                    const u64 ol = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(ql >> 32), (int)x) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)ql, (int)x);
+                    u64 oh = 0;
+                    if (KW == 2) oh = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(qh >> 32), (int)x) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)qh, (int)x);
+                    const bool less = key_less(oh, ol, hi, lo);
+                    const bool eq = oh == hi && ol == lo;
+                    rk += (less || (eq && (e + x) < i)) ? 1u : 0u;
                 }
-                if (have) { L.a_lo[o + rk] = lo; if (KW == 2) L.a_hi[o + rk] = hi; if (WEIGHTS) L.a_w[o + rk] = w; }
             }
-        } else {
-            if (lane == 0) L.bad = 1;
+            if (have) { L.a_lo[o + rk] = lo; if (KW == 2) L.a_hi[o + rk] = hi; if (WEIGHTS) L.a_w[o + rk] = w; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (u32 i = lane; i < m; i += 64) {       // back into b (this wave's own bucket)
+            L.b_lo[o + i] = L.a_lo[o + i];
+            if (KW == 2) L.b_hi[o + i] = L.a_hi[o + i];
+            if (WEIGHTS) L.b_w[o + i] = L.a_w[o + i];
         }
     }
     __syncthreads();
     if (L.bad) {
-        // a sub-bucket of more than 1024 keys that are not all equal at this digit (heavily repeated
-        // keys next to others): sort the whole leaf with a bitonic network in LDS (rare; b is the source)
+        // a sub-bucket of more than 1024 keys that differ (heavily repeated keys next to others): sort
+        // the whole leaf with a bitonic network in LDS (rare).  Source b, network in a, result back in b.
         u32 P = 1;
         while (P < n) P <<= 1;
         for (u32 i = tid; i < P; i += KMC_MSD_THREADS) {
@@ -546,19 +670,24 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
                 __syncthreads();
             }
         }
+        for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
+            L.b_lo[i] = L.a_lo[i];
+            if (KW == 2) L.b_hi[i] = L.a_hi[i];
+            if (WEIGHTS) L.b_w[i] = L.a_w[i];
+        }
+        __syncthreads();
     }
-    // 4. run-length over the sorted image a[0..n): heads get the sum of their run's weights
-    //    (b is free: heads are compacted into it, then copied out)
+    // 4. run-length over the sorted image b[0..n): every head writes its (key, sum of the run's weights)
+    //    pair straight to the staging arrays at its ordinal among the heads
     for (u32 c0 = 0; c0 < n; c0 += KMC_MSD_THREADS * 4) {
-        // each thread owns 4 consecutive elements of this slab
-        const u32 i0 = c0 + tid * 4;
+        const u32 i0 = c0 + tid * 4;  // each thread owns 4 consecutive elements of this slab
         u32 nh = 0;
         bool head[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const u32 i = i0 + e;
             bool h = false;
-            if (i < n) h = i == 0 || L.a_lo[i] != L.a_lo[i - 1] || (KW == 2 && L.a_hi[i] != L.a_hi[i - 1]);
+            if (i < n) h = i == 0 || L.b_lo[i] != L.b_lo[i - 1] || (KW == 2 && L.b_hi[i] != L.b_hi[i - 1]);
             head[e] = h;
             nh += h ? 1u : 0u;
         }
@@ -577,10 +706,10 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             if (i < n && head[e]) {
                 u64 s = 0;
                 u32 j = i;
-                do { s += WEIGHTS ? L.a_w[j] : 1ull; ++j; } while (j < n && L.a_lo[j] == L.a_lo[i] && (KW == 1 || L.a_hi[j] == L.a_hi[i]));
-                L.b_lo[pos] = L.a_lo[i];
-                if (KW == 2) L.b_hi[pos] = L.a_hi[i];
-                L.b_w[pos] = s;
+                do { s += WEIGHTS ? L.b_w[j] : 1ull; ++j; } while (j < n && L.b_lo[j] == L.b_lo[i] && (KW == 1 || L.b_hi[j] == L.b_hi[i]));
+                t_lo[T.begin + pos] = L.b_lo[i];
+                if (KW == 2) t_hi[T.begin + pos] = L.b_hi[i];
+                t_cnt[T.begin + pos] = s;
                 ++pos;
             }
         }
@@ -588,14 +717,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         if (tid == KMC_MSD_THREADS - 1) L.n_out = pos;  // (the last thread's end = the slab's end)
         __syncthreads();
     }
-    const u32 n_out = L.n_out;
-    for (u32 i = tid; i < n_out; i += KMC_MSD_THREADS) {
-        t_lo[T.begin + i] = L.b_lo[i];
-        if (KW == 2) t_hi[T.begin + i] = L.b_hi[i];
-        t_cnt[T.begin + i] = L.b_w[i];
-    }
-    if (tid == 0) nd[t] = n_out;
-    (void)CAP;
+    if (tid == 0) nd[t] = L.n_out;
 }
 
 // dense run: terminal t's nd[t] pairs move from its span of the staging arrays to base[t]

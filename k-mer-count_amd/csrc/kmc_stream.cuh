@@ -140,9 +140,11 @@ __device__ __attribute__((noinline)) u32 stream_drain(StreamLds<KW>& L, const GT
     return nglobal;
 }
 
-// hot path: one k-mer per lane.  Returns the new fill of the wave's miss buffer (wave-uniform).
+// hot path: one k-mer per lane, straight-line (no branch, so that the sixteen steps of a chunk overlap:
+// the next step's hash and LDS reads are issued while this step's compare waits).  Returns true when
+// a valid window found its key in neither home slot; the caller collects those per chunk.
 template <int KW>
-__device__ __forceinline__ u32 stream_count(StreamLds<KW>& L, int wv, u64 hi, u64 lo, bool ok, u32 nbuf) {
+__device__ __forceinline__ bool stream_probe(StreamLds<KW>& L, u64 hi, u64 lo, bool ok) {
     const u32 h = stream_home<KW>(hi, lo);
     bool m0, m1;
     if (KW == 1) {
@@ -161,21 +163,10 @@ __device__ __forceinline__ u32 stream_count(StreamLds<KW>& L, int wv, u64 hi, u6
         m0 = h0 == hi && l0 == lo;
         m1 = h1 == hi && l1 == lo;
     }
-    // branch-free add: every lane adds to one of its home counters, 1 on a hit of a valid window and 0
-    // otherwise (a per-lane branch around the ds_add cost four scalar instructions per step)
+    // branch-free add: every lane adds to one of its home counters, 1 on a hit of a valid window and 0 otherwise
     const bool hit = ok && (m0 || m1);
     atomicAdd(&L.cnt[h + (m0 ? 0u : 1u)], hit ? 1u : 0u);
-    const bool miss = ok && !hit;
-    const u64 mb = __builtin_amdgcn_ballot_w64(miss);
-    if (mb != 0) {  // wave-uniform
-        if (miss) {
-            const u32 idx = nbuf + __builtin_amdgcn_mbcnt_hi((u32)(mb >> 32), __builtin_amdgcn_mbcnt_lo((u32)mb, 0u));
-            L.miss[wv][idx].lo = lo;
-            if constexpr (KW == 2) L.miss[wv][idx].hi = hi;
-        }
-        nbuf += (u32)__popcll(mb);
-    }
-    return nbuf;
+    return ok && !hit;
 }
 
 // wide bit masks for the validity smear: 64 bits cover the 48-base window of KW==1,
@@ -366,6 +357,7 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                     }
                     u64* const o_lo = SINK == 1 ? out_lo + (pp - chunk_begin * KMC_CHUNK) : nullptr;
                     u64* const o_hi = (SINK == 1 && KW == 2) ? out_hi + (pp - chunk_begin * KMC_CHUNK) : nullptr;
+                    u32 missmask = 0;  // bit j: this lane's window j missed both home slots
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int s = 30 - 2 * j;
@@ -385,19 +377,35 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         }
                         const bool ok = !((inv16 >> j) & 1);
                         if constexpr (SINK == 0) {
-                            nk += ok;
-                            const u32 nb1 = stream_count<KW>(L, wv, khi, klo, ok, nbuf);
-                            if (nb1 != nbuf) {  // wave-uniform: some lane missed
-                                nbuf = nb1;
-                                if (nbuf > KMC_STREAM_MISSBUF - 64) {  // no room for another full step
-                                    nglobal += stream_drain<KW, CANON>(L, g, wv, lane, nbuf, k);
-                                    nbuf = 0;
-                                }
-                            }
+                            missmask |= stream_probe<KW>(L, khi, klo, ok) ? (1u << j) : 0u;
                         } else {
                             o_lo[j] = ok ? klo : ~0ull;
                             if (KW == 2) o_hi[j] = ok ? khi : ~0ull;
                             nk += ok;
+                        }
+                    }
+                    if constexpr (SINK == 0) {
+                        nk += (u32)__popc(~inv16 & 0xFFFFu);
+                        // the chunk's misses (first sight of a key, keys that did not fit their home bucket):
+                        // one per lane and round into the wave's miss buffer; the drain inserts them
+                        u64 mb;
+                        while ((mb = __builtin_amdgcn_ballot_w64(missmask != 0)) != 0) {
+                            if (missmask != 0) {
+                                const int jm = __ffs((int)missmask) - 1;
+                                missmask &= missmask - 1;
+                                const u32 sh = 30u - 2u * (u32)jm;
+                                u32 f[2 * KW];
+#pragma unroll
+                                for (int m = 0; m < 2 * KW; ++m) f[m] = alignbit(X[m + 1], X[m], sh);
+                                const u32 idx = nbuf + __builtin_amdgcn_mbcnt_hi((u32)(mb >> 32), __builtin_amdgcn_mbcnt_lo((u32)mb, 0u));
+                                L.miss[wv][idx].lo = ((u64)f[1] << 32 | f[0]) & mask_lo;
+                                if constexpr (KW == 2) L.miss[wv][idx].hi = ((u64)f[3] << 32 | f[2]) & mask_hi;
+                            }
+                            nbuf += (u32)__popcll(mb);
+                            if (nbuf > KMC_STREAM_MISSBUF - 64) {  // no room for another round
+                                nglobal += stream_drain<KW, CANON>(L, g, wv, lane, nbuf, k);
+                                nbuf = 0;
+                            }
                         }
                     }
                 }

@@ -43,6 +43,24 @@ __global__ void kmc_reset_kernel(GTable g) {
     if (blockIdx.x == 0 && threadIdx.x < KMC_CTR_N) g.counters[threadIdx.x] = 0;
 }
 
+// The table as it is before a launch whose size rests on a PREDICTION of how many new keys it brings
+// (kmc_api.hip, launch planner): the claimed slots are listed in occ_list while there are at most
+// occ_list_cap of them, so a small table is saved by copying those entries -- a few microseconds.
+// *s_n = number of entries saved, or ~0 when the table is too large for this form.
+template <int KW>
+__global__ void kmc_snapshot_kernel(GTable g, u64* __restrict__ s_hi, u64* __restrict__ s_lo, u64* __restrict__ s_cnt, u64* __restrict__ s_n) {
+    const u64 n = g.counters[KMC_CTR_OCCUPIED];
+    const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n > g.occ_list_cap) { if (i0 == 0) *s_n = ~0ull; return; }
+    for (u64 i = i0; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 slot = g.occ_list[i];
+        s_lo[i] = g.key_lo[slot];
+        s_cnt[i] = g.count[slot];
+        if (KW == 2) s_hi[i] = g.key_hi[slot];
+    }
+    if (i0 == 0) *s_n = n;
+}
+
 // re-insert every entry of `old` into `g` (growth)
 template <int KW>
 __global__ void kmc_rehash_kernel(GTable old, GTable g) {

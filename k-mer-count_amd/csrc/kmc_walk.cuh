@@ -59,15 +59,16 @@
 struct WalkNode {
     u64 prim;  // low 32: label = 16 bases, 2 bits each, first base in the low bits (internal code
                // A0 C1 T2 G3); high 32: byte offset (id*16) of the successor node, 0 = no primary yet
-    u32 cnt;   // traversals of the primary edge
-    u32 pad;
+    u32 cnt[2];  // traversals of the primary edge: even lanes count in [0], odd lanes in [1].  All lanes of
+                 // a wave are at the same phase of their reads, i.e. on the same few nodes, and same-address
+                 // LDS atomics of one instruction serialise (64 % of the LDS cycles were conflict cycles with
+                 // one counter); the second counter lives in what was padding
 };
 // Secondary edges (other continuations, and the <16-base step that ends a read): hashed.
 // kv = label(32) | (len-1)<<32 (4 bits) | node<<36 (11 bits) | succ<<47 (11 bits); ~0 = empty
 struct WalkEdge {
     u64 kv;
-    u32 cnt;
-    u32 pad;
+    u32 cnt[2];  // as WalkNode::cnt
 };
 #define KMC_EDGE_KEYMASK ((1ull << 47) - 1)
 
@@ -246,12 +247,81 @@ __device__ __forceinline__ u32 walk_node(WalkLds<KW>& L, WCtx nk) {
     return res;
 }
 
+// ---- second level of the memo: the stride-16 "super-k-mer" table in global memory -----------------------
+// When the LDS memo is full, a full step from a k-mer context used to be counted as 16 separate k-mers
+// with 16 global atomics (and KMC_ALGO_AUTO gave the input up to the sort path as soon as 5 % of the
+// k-mers went that way: a 100-400x cliff between a pool of 20 and a pool of 26 lines).  Such a step is
+// fully described by ONE (k+16)-mer -- the context followed by the 16 bases of the step -- so it is now
+// counted as one add into a second global table keyed by that (k+16)-mer (two words: k <= 47), one
+// global atomic per 16 bases; kmc_sk_unfold_kernel later gives the count to each of the (k+16)-mer's
+// last 16 k-mers, once per distinct (k+16)-mer instead of once per occurrence.  Additive, so exact.
+// The table keeps its keys across launches (like the LDS memo) and is cleared by kmc_forget_source.
+#define KMC_SK_MAX_K 47
+// the (k+16)-mer of a step: context (2k bits, public code, newest base lowest) followed by the label
+// (16 bases, internal code, first base in the low bits)
+__device__ __forceinline__ void sk_key(WCtx ctx, u32 label, u64& hi, u64& lo) {
+    const u32 pub = label ^ ((label >> 1) & 0x55555555u);  // A0 C1 T2 G3 -> A0 C1 G2 T3
+    const u32 be = le_to_be(pub);                           // first base of the step in the top bits
+    hi = (ctx.hi << 32) | (ctx.lo >> 32);
+    lo = (ctx.lo << 32) | be;
+}
+
+// every (k+16)-mer with a count gives it to its last 16 k-mers; counts are cleared for the next launch
+template <int KW, bool CANON>
+__global__ __launch_bounds__(256)
+void kmc_sk_unfold_kernel(GTable sk, int k, GTable g) {
+    const u64 cap = sk.capmask + 1;
+    const int kb = 2 * k;
+    const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
+    const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
+    // item = (slot, j): the k-mer that ends j bases before the end of the (k+16)-mer, j = 0..15
+    for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < cap * 16; w += (u64)gridDim.x * blockDim.x) {
+        const u64 slot = w >> 4;
+        const u32 j = (u32)w & 15u;
+        const u64 c = sk.count[slot];
+        if (c) {
+            const u64 hi = sk.key_hi[slot], lo = sk.key_lo[slot];
+            const u32 sh = 2 * j;  // drop the last j bases
+            WCtx km;
+            km.lo = (sh ? ((lo >> sh) | (hi << (64 - sh))) : lo) & mask_lo;
+            km.hi = KW == 2 ? ((hi >> sh) & mask_hi) : 0ull;
+            walk_gadd<KW, CANON>(g, km, k, c);
+        }
+        // the 16 items of a slot sit in 16 consecutive lanes: all have read the count before lane j == 0 clears it
+        __builtin_amdgcn_wave_barrier();
+        if (c && j == 0) sk.count[slot] = 0;
+    }
+    // (k+16)-mers that found no slot within the probe budget wait in the table's spill area
+    const u64 n_spill = min(sk.counters[KMC_CTR_SPILL], sk.spill_cap);
+    for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_spill * 16; w += (u64)gridDim.x * blockDim.x) {
+        const u64 e = w >> 4;
+        const u32 sh = 2 * ((u32)w & 15u);
+        const u64 hi = sk.spill_hi[e], lo = sk.spill_lo[e], c = sk.spill_cnt[e];
+        WCtx km;
+        km.lo = (sh ? ((lo >> sh) | (hi << (64 - sh))) : lo) & mask_lo;
+        km.hi = KW == 2 ? ((hi >> sh) & mask_hi) : 0ull;
+        if (c) walk_gadd<KW, CANON>(g, km, k, c);
+    }
+}
+// (the spill counter is cleared by a second, tiny launch: every workgroup of the unfold reads it)
+__global__ void kmc_sk_spill_reset_kernel(GTable sk) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) sk.counters[KMC_CTR_SPILL] = 0;
+}
+
 // Slow path of one step from node offset `s` (s == 0: direct mode).  Returns the next state.
 template <int KW, bool CANON>
 __device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s, u32 label, int len, int k,
-                                         u64 mask_hi, u64 mask_lo, WCtx& dctx, u32& ddepth, u64& ndirect) {
-    if (s == 0) {  // direct mode: roll the context and count every k-mer with a global atomic
-        ndirect += walk_roll<KW, CANON, true>(g, dctx, ddepth, label, len, k, mask_hi, mask_lo, 1);
+                                         u64 mask_hi, u64 mask_lo, WCtx& dctx, u32& ddepth, u64& ndirect, u32 cpar, const GTable& sk) {
+    if (s == 0) {  // direct mode: no node of the LDS memo stands for this lane's context
+        if (sk.key_lo && len == KMC_WALK_STRIDE && ddepth >= (u32)k) {
+            // a full step from a k-mer context: one add of its (k+16)-mer (second-level memo, above)
+            u64 shi, slo;
+            sk_key(dctx, label, shi, slo);
+            gtable_add<2>(sk, shi, slo, 1);
+            (void)walk_roll<KW, CANON, false>(g, dctx, ddepth, label, len, k, mask_hi, mask_lo, 0);
+        } else {
+            ndirect += walk_roll<KW, CANON, true>(g, dctx, ddepth, label, len, k, mask_hi, mask_lo, 1);
+        }
         return 0;
     }
     const u32 id = s >> 4;
@@ -280,7 +350,7 @@ __device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s,
             }
         }
         if ((u32)pe == label && (u32)(pe >> 32) != 0) {
-            atomicAdd(&np->cnt, 1u);
+            atomicAdd(&np->cnt[cpar], 1u);
             return (u32)(pe >> 32);
         }
     }
@@ -294,7 +364,7 @@ __device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s,
         if (!done) {
             u64 kv = __hip_atomic_load(&L.edge[hh].kv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (((kv ^ key) & KMC_EDGE_KEYMASK) == 0 && kv != ~0ull) {
-                atomicAdd(&L.edge[hh].cnt, 1u);
+                atomicAdd(&L.edge[hh].cnt[cpar], 1u);
                 val = (u32)(kv >> 47);
                 found = true;
                 done = true;
@@ -308,7 +378,7 @@ __device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s,
                     u64 old = atomicCAS((unsigned long long*)&L.edge[hh].kv, ~0ull, want);
                     if (old == ~0ull) {
                         atomicAdd(&L.nedges, 1u);
-                        atomicAdd(&L.edge[hh].cnt, 1u);
+                        atomicAdd(&L.edge[hh].cnt[cpar], 1u);
                         val = sid;
                         found = true;
                         done = true;
@@ -322,11 +392,19 @@ __device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s,
         }
     }
     if (found) return val << 4;  // (a <16-base step ends the read; its successor is unused)
-    // 3. memo full: count this step's k-mers directly from the node's context
+    // 3. memo full: count this step from the node's context -- as ONE (k+16)-mer in the second-level table
+    //    when it is a full step from a k-mer context, k-mer by k-mer otherwise
     WCtx ctx;
     u32 depth;
     node_decode<KW>(node_key_load<KW>(L, id), k, ctx, depth);
-    ndirect += walk_roll<KW, CANON, true>(g, ctx, depth, label, len, k, mask_hi, mask_lo, 1);
+    if (sk.key_lo && len == KMC_WALK_STRIDE && depth >= (u32)k) {
+        u64 shi, slo;
+        sk_key(ctx, label, shi, slo);
+        gtable_add<2>(sk, shi, slo, 1);
+        (void)walk_roll<KW, CANON, false>(g, ctx, depth, label, len, k, mask_hi, mask_lo, 0);
+    } else {
+        ndirect += walk_roll<KW, CANON, true>(g, ctx, depth, label, len, k, mask_hi, mask_lo, 1);
+    }
     if (len != KMC_WALK_STRIDE) return 0;
     if (!have_succ) make_succ();
     if (sid) return sid << 4;  // successor node exists: stay on the memoised path
@@ -363,21 +441,23 @@ template <int KW, bool CANON>
 __global__ __launch_bounds__(KMC_WALK_THREADS)
 void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ vstart, const u64* __restrict__ vend, u64 n_reads,
                      int k, u64 tile_begin, u64 tile_end, WalkWs* ws, u32* deferred, const WalkMemoSlot<KW>* memo,
-                     WalkMemoSlot<KW>* memo_out, u64* gcnt, GTable g) {
+                     WalkMemoSlot<KW>* memo_out, u64* gcnt, GTable g, GTable sk) {
     extern __shared__ __align__(16) unsigned char walk_smem[];
     WalkLds<KW>& L = *reinterpret_cast<WalkLds<KW>*>(walk_smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 cpar = (u32)lane & 1u;  // which of the two traversal counters of a node / edge this lane uses
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
 
     const bool warm = memo && memo->tag == (KMC_WALK_MEMO_TAG | (u64)k);  // workgroup-uniform
-    for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) { L.edge[i].kv = warm ? memo->ekv[i] : ~0ull; L.edge[i].cnt = 0; }
+    for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) { L.edge[i].kv = warm ? memo->ekv[i] : ~0ull; L.edge[i].cnt[0] = 0; L.edge[i].cnt[1] = 0; }
     for (int i = tid; i < KMC_WALK_NCAP; i += KMC_WALK_THREADS) {
         L.nkeys[i] = warm ? memo->nkeys[i] : (KW == 1 ? KMC_EMPTY64 : 0ull);
         if (KW == 2) L.nkeys_hi[i] = warm ? memo->nkeys_hi[i] : KMC_EMPTY64;
         L.node[i].prim = warm ? memo->prim[i] : 0ull;
-        L.node[i].cnt = 0;
+        L.node[i].cnt[0] = 0;
+        L.node[i].cnt[1] = 0;
     }
     if (tid == 0) { L.nedges = warm ? memo->nedges : 0; L.nnodes = warm ? memo->nnodes : 1; L.qnext = KMC_WALK_WAVES; }
     __syncthreads();
@@ -560,11 +640,11 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
                 WalkNode* np = reinterpret_cast<WalkNode*>(reinterpret_cast<char*>(L.node) + s);
                 const u64 pe = __hip_atomic_load(&np->prim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (full && (u32)pe == label && (u32)(pe >> 32) != 0) {
-                    atomicAdd(&np->cnt, 1u);
+                    atomicAdd(&np->cnt[cpar], 1u);
                     s = (u32)(pe >> 32);
                 } else {
                     if (!full) label &= (1u << (2 * tail)) - 1u;
-                    s = walk_slow<KW, CANON>(L, g, s, label, full ? KMC_WALK_STRIDE : (int)tail, k, mask_hi, mask_lo, dctx, ddepth, ndirect);
+                    s = walk_slow<KW, CANON>(L, g, s, label, full ? KMC_WALK_STRIDE : (int)tail, k, mask_hi, mask_lo, dctx, ddepth, ndirect, cpar, sk);
                 }
             }
         }
@@ -652,10 +732,10 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         u32 cnt;
         bool snap;  // the entry came with the shared snapshot (it cannot have changed since: set-once fields)
         if (i < KMC_WALK_NCAP) {
-            cnt = ((L.node[i].prim >> 32) != 0) ? L.node[i].cnt : 0;
+            cnt = ((L.node[i].prim >> 32) != 0) ? L.node[i].cnt[0] + L.node[i].cnt[1] : 0;
             snap = warm && (memo->prim[i] >> 32) != 0;
         } else {
-            cnt = (L.edge[i - KMC_WALK_NCAP].kv != ~0ull) ? L.edge[i - KMC_WALK_NCAP].cnt : 0;
+            cnt = (L.edge[i - KMC_WALK_NCAP].kv != ~0ull) ? L.edge[i - KMC_WALK_NCAP].cnt[0] + L.edge[i - KMC_WALK_NCAP].cnt[1] : 0;
             snap = warm && memo->ekv[i - KMC_WALK_NCAP] != ~0ull;
         }
         if (cnt) {
@@ -674,10 +754,10 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         const u32 i = flist[w / KMC_WALK_STRIDE], step = w % KMC_WALK_STRIDE;
         u32 label, len, id, cnt;
         if (i < KMC_WALK_NCAP) {
-            id = i; label = (u32)L.node[i].prim; len = KMC_WALK_STRIDE; cnt = L.node[i].cnt;
+            id = i; label = (u32)L.node[i].prim; len = KMC_WALK_STRIDE; cnt = L.node[i].cnt[0] + L.node[i].cnt[1];
         } else {
             const u64 kv = L.edge[i - KMC_WALK_NCAP].kv;
-            cnt = L.edge[i - KMC_WALK_NCAP].cnt;
+            cnt = L.edge[i - KMC_WALK_NCAP].cnt[0] + L.edge[i - KMC_WALK_NCAP].cnt[1];
             label = (u32)kv; len = ((u32)(kv >> 32) & 15u) + 1; id = (u32)(kv >> 36) & (KMC_WALK_NCAP - 1);
         }
         if (step < len) {
@@ -820,19 +900,25 @@ static inline size_t kmc_walk_workspace_bytes(u64 n_reads) { return KMC_WALK_WS_
 
 template <int KW, bool CANON>
 static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const uint8_t* d_bases, const u64* d_vstart, const u64* d_vend,
-                                     u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, u64* gcnt, void* memo, int parity, GTable g, int phase) {
+                                     u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, u64* gcnt, void* memo, int parity, GTable g, GTable sk, int phase) {
     const size_t smem = sizeof(WalkLds<KW>);
     static bool attr = false;  // one flag per instantiation
     if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<KW, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
     WalkMemoSlot<KW>* slots = (WalkMemoSlot<KW>*)memo;
     if (phase == 0) {
         hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_vstart, d_vend, n_reads, k, tile_begin, tile_end, hdr, list,
-                           (const WalkMemoSlot<KW>*)&slots[parity], &slots[parity ^ 1], gcnt, g);
+                           (const WalkMemoSlot<KW>*)&slots[parity], &slots[parity ^ 1], gcnt, g, sk);
     } else {
         hipLaunchKernelGGL((kmc_scalar_reads_kernel<KW, CANON>), dim3(n_cu), dim3(256), 0, st, d_bases, d_vstart, d_vend, hdr, list, k, g);
         static_assert(((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE) % 256 == 0 && 256 % KMC_WALK_STRIDE == 0, "unfold grid must cover the items exactly");
         hipLaunchKernelGGL((kmc_walk_unfold_kernel<KW, CANON>), dim3((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE / 256), dim3(256), 0, st,
                            (const WalkMemoSlot<KW>*)&slots[parity], gcnt, hdr, k, g);
+        if (sk.key_lo) {
+            const u64 items = (sk.capmask + 1) * 16;
+            const u64 blocks = (items + 255) / 256;
+            hipLaunchKernelGGL((kmc_sk_unfold_kernel<KW, CANON>), dim3((unsigned)(blocks < (u64)n_cu * 16 ? blocks : (u64)n_cu * 16)), dim3(256), 0, st, sk, k, g);
+            hipLaunchKernelGGL(kmc_sk_spill_reset_kernel, dim3(1), dim3(64), 0, st, sk);
+        }
     }
 }
 
@@ -843,7 +929,7 @@ static inline int kmc_walk_prepare(hipStream_t st, void* ws) {
     return hipMemsetAsync(ws, 0, KMC_WALK_WS_PREFIX, st) == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
 static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool canon, const uint8_t* d_bases,
-                                  const u64* d_vstart, const u64* d_vend, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, int parity, GTable g, int phase) {
+                                  const u64* d_vstart, const u64* d_vend, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, int parity, GTable g, GTable sk, int phase) {
     if (n_reads >= (1ull << 32) || tile_end <= tile_begin) return KMC_ERR_ARG;
     WalkWs* hdr = (WalkWs*)ws;
     u32* list = (u32*)((char*)ws + KMC_WALK_WS_PREFIX);
@@ -853,11 +939,11 @@ static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool 
     int grid = (int)(want < (u64)n_cu ? want : (u64)n_cu);  // one 160 KB workgroup per CU is resident
     if (grid < 1) grid = 1;
     if (KW == 1) {
-        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
-        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
+        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, phase);
+        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, phase);
     } else {
-        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
-        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, phase);
+        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, phase);
+        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, phase);
     }
     return hipGetLastError() == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }

@@ -137,9 +137,18 @@ def _same_stream(ctx, dev) -> bool:
     return bool(ctx.stream) and ctx.stream == torch.cuda.current_stream(dev).cuda_stream
 
 
-def _order(ctx, dev):
-    """Order torch's current stream and the ctx stream with respect to each other."""
-    if dev.type == "cuda" and not _same_stream(ctx, dev):
+def _order(ctx, dev, ctx_first: bool):
+    """Order the ctx's stream and torch's current stream (the one the collective runs on) with respect
+    to each other.  Nothing to do when the ctx queues its work on torch's current stream.  Otherwise
+    ctx_first=True: everything queued on the ctx (the slab pack kernel) has finished before torch's
+    stream goes on -- a ctx created without stream= runs on its OWN non-blocking stream, which a
+    synchronize of torch's stream does not cover (the all-gather would read a slab that is still being
+    written); ctx_first=False: torch's stream (the collective) has finished before the ctx goes on."""
+    if dev.type != "cuda" or _same_stream(ctx, dev):
+        return
+    if ctx_first:
+        ctx.sync()
+    else:
         torch.cuda.current_stream(dev).synchronize()
 
 
@@ -183,9 +192,9 @@ def reduce_tables(local, owner, group=None, slab_entries: int = SLAB_ENTRIES, re
     words = local.slab_words(slab_entries)
     slab, gathered = _slab_buffers(words, world, dev)
     local.pack_slab_device(slab.data_ptr(), slab_entries)
-    _order(local, dev)                      # slab written before the collective reads it
+    _order(local, dev, ctx_first=True)      # slab written before the collective reads it
     _all_gather_slabs(gathered, slab, group)
-    _order(owner, dev)                      # gathered slabs landed before the owner's stream reads them
+    _order(owner, dev, ctx_first=False)     # gathered slabs landed before the owner's stream reads them
     owner.merge_slabs_device(gathered.data_ptr(), world, slab_entries, rank, world)
     got, _ = owner.finalize()
     if local.stats().launches_last != 1:

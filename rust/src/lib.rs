@@ -94,6 +94,7 @@ extern "C" {
     pub fn kmc_pack_slab_device(ctx: *mut KmcCtx, d_slab: *mut c_void, slab_entries: u64) -> c_int;
     pub fn kmc_merge_slabs_device(ctx: *mut KmcCtx, d_slabs: *const c_void, n_slabs: u32, slab_entries: u64, my_part: u32, n_parts: u32) -> c_int;
     pub fn kmc_poll(ctx: *mut KmcCtx) -> c_int;
+    pub fn kmc_sync(ctx: *mut KmcCtx) -> c_int;
     pub fn kmc_read_pieces(read_len: u64, k: c_int, starts: *mut u64, ends: *mut u64, cap: u64) -> u64;
     pub fn kmc_forget_source(ctx: *mut KmcCtx, what: c_int) -> c_int;
     pub fn kmc_get_stats(ctx: *const KmcCtx, out: *mut KmcStats) -> c_int;

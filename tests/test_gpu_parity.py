@@ -433,6 +433,24 @@ def test_rccl_reduce_single_rank(kmc, oracle):
                 sent, got = kd.reduce_tables(local, owner)
                 assert sent == got == want.n_distinct
                 assert owner.export().equals(want)
+        # ctxs on their OWN streams (no stream= argument) with a long batch queued right in front of the
+        # slab pack: the collective must wait for the ctx stream (kmc_sync), not only for torch's stream --
+        # otherwise it reads the cached slab buffer before the pack kernel has written it (stale / zero slab)
+        s = kmc.Synth(seed=4)
+        n = 1_500_000
+        d_b = torch.empty(n * 400 + 64, dtype=torch.uint8, device="cuda")
+        d_o = torch.empty(n + 1, dtype=torch.int64, device="cuda")
+        kmc.synth_reads_device(s, 0, n, d_b.data_ptr(), d_o.data_ptr())
+        import analytic_oracle as ao
+        want = ao.exact_table(4, 31, 0, n, True)
+        with kmc.KmerCounter(k=31, algo=kmc.ALGO_STREAM) as local, kmc.KmerCounter(k=31) as owner:
+            for rep in range(3):
+                local.reset()
+                owner.reset()
+                local.add_batch_device(d_b.data_ptr(), d_o.data_ptr(), n, n * 400, 400)  # several ms of kernel time, asynchronous
+                sent, got = kd.reduce_tables(local, owner)
+                assert sent == got == want.n_distinct, rep
+                assert owner.export().equals(want), rep
     finally:
         dist.destroy_process_group()
 
@@ -894,3 +912,42 @@ def test_msd_sort_path_matches_oracle(kmc, oracle, k, pool, n_rec):
         kc.add_batch(hb[:h * 400], ho[:h + 1])
         kc.add_batch(hb[h * 400:], ho[h:] - ho[h])
         assert kc.export().equals(oracle.count_kmers(hb, ho, k, True, method=1))
+
+
+@pytest.mark.parametrize("algo_name", ["auto", "walk", "stream"])
+def test_wrong_prediction_is_recovered_not_fatal(kmc, oracle, algo_name):
+    """The launch planner sizes a batch's launches from what earlier batches (and earlier launches of the
+    same batch) looked like.  A low-cardinality batch followed by a high-cardinality one on the same ctx,
+    and a batch that starts with repeats / N runs and then turns random, used to exhaust table and spill
+    area in one oversized launch and fail with KMC_ERR_CAPACITY.  Now the table is saved in front of such
+    a launch, put back when the spill area overflows, and the rest of the batch is counted by sorting:
+    exact tables, no error."""
+    algo = {"auto": kmc.ALGO_AUTO, "walk": kmc.ALGO_WALK, "stream": kmc.ALGO_STREAM}[algo_name]
+    k = 31
+    lo_b, lo_o = kmc.synth_reads_host(kmc.Synth(seed=21, pool=10), 0, 300_000)      # 3.4 k distinct
+    hi_b, hi_o = kmc.synth_reads_host(kmc.Synth(seed=22, pool=0), 0, 12_000)        # 4.4 M distinct, far beyond table + spill
+    both_b = np.concatenate([lo_b, hi_b])
+    both_o = np.concatenate([lo_o, hi_o[1:] + lo_o[-1]])
+    want = oracle.count_kmers(both_b, both_o, k, True, method=1)
+    # (1) two batches on one ctx: the second goes out in ONE launch on the history of the first
+    with kmc.KmerCounter(k=k, algo=algo) as kc:
+        kc.add_batch(lo_b, lo_o)
+        kc.finalize()
+        assert kc.stats().launches_last >= 1
+        kc.add_batch(hi_b, hi_o)
+        got = kc.export()
+        assert got.equals(want)
+        assert kc.stats().n_kmers == want.n_total
+        # the ctx keeps working afterwards
+        kc.reset()
+        kc.add_batch(lo_b, lo_o)
+        assert kc.export().equals(oracle.count_kmers(lo_b, lo_o, k, True, method=1))
+    # (2) one batch: a long run of N and repeats first (launches ramp up on "no new keys"), then random reads
+    n_b = np.full(400 * 50_000, ord("N"), np.uint8)
+    n_o = (np.arange(50_001, dtype=np.uint64) * np.uint64(400))
+    mix_b = np.concatenate([n_b, lo_b, hi_b])
+    mix_o = np.concatenate([n_o, lo_o[1:] + n_o[-1], hi_o[1:] + n_o[-1] + lo_o[-1]])
+    with kmc.KmerCounter(k=k, algo=algo) as kc:
+        kc.forget_source(memo=True, history=True)
+        kc.add_batch(mix_b, mix_o)
+        assert kc.export().equals(want)
