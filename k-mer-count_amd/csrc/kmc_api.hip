@@ -12,7 +12,6 @@
 #include <cstring>
 
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include <algorithm>
 #include <new>
@@ -26,7 +25,6 @@
 #include "kmc_table.cuh"
 #include "kmc_walk.cuh"
 #include "kmc_lr.cuh"
-#include "kmc_sort.cuh"
 #include "kmc_msd.cuh"
 #include "kmc_ingest.h"
 
@@ -65,7 +63,7 @@ struct kmc_ctx {
     // staging for host batches
     DevBuf st_bases, st_offsets;
     // sorted view
-    DevBuf o_hi, o_lo, o_cnt, t_hi, t_lo, t_cnt, t_idx0, t_idx1, t_key, sort_tmp, p_hi, p_lo, p_cnt;
+    DevBuf o_hi, o_lo, o_cnt, t_hi, t_lo, t_cnt, t_idx0, p_hi, p_lo, p_cnt;
     u64 n_sorted = 0;
     bool sorted_valid = false;
     // walk-kernel workspace
@@ -75,13 +73,14 @@ struct kmc_ctx {
     int memo_parity = 0;  // snapshot slot the next walk launch reads
     bool walk_ws_clean = false;  // workspace header + dense counters are zero (left so by kmc_walk_unfold_kernel)
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
-    DevBuf s_lo[2], s_hi[2], s_flags, s_pos, s_head;
+    DevBuf s_lo[2], s_hi[2];
     // hand-written MSD radix sort (kmc_msd.cuh): per-range histograms, segment lists, terminals
     DevBuf m_hist, m_stot, m_bsum, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_cnt, m_w[2];
     MsdCtl* h_ctl = nullptr;  // pinned mirror of the sort's device counters
     struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0, cap = 0; u64 total = 0; bool total_known = false; };
     std::vector<Run> runs;       // live runs
     std::vector<Run> run_pool;   // buffers of dropped runs, reused (multi-GB hipMalloc/hipFree per batch is slow)
+    Run view_run;                // the merged, sorted view built by the last kmc_finalize (table entries + runs)
     const u64 *v_hi = nullptr, *v_lo = nullptr, *v_cnt = nullptr;  // the sorted view of the last finalize
     bool prefer_sort = false;  // AUTO: the data source proved high-cardinality  // per-workgroup memo slots, kept across launches (kmc_walk.cuh)
 
@@ -120,6 +119,7 @@ struct kmc_ctx {
     u64* h_sk_counters = nullptr;   // pinned mirror (valid after a poll)
     u64 *sk_spill_hi = nullptr, *sk_spill_lo = nullptr, *sk_spill_cnt = nullptr;
     u64 sk_spill_cap = 0;
+    u64* sk_occ = nullptr;          // list of its claimed slots (what the unfold kernel walks)
     bool recovered = false;  // the last poll found an overflow and recovered: the batch in flight is complete
 };
 
@@ -187,6 +187,7 @@ int alloc_table(kmc_ctx* c, Table& t, u64 cap) {
 void free_runs(kmc_ctx* c, bool release = false) {
     for (auto& r : c->runs) { r.n = 0; c->run_pool.push_back(r); }
     c->runs.clear();
+    if (c->view_run.lo) { c->view_run.n = 0; c->run_pool.push_back(c->view_run); c->view_run = kmc_ctx::Run{}; }
     if (release) {
         for (auto& r : c->run_pool) {
             if (r.hi) (void)hipFree(r.hi);
@@ -256,8 +257,8 @@ GTable sk_table_of(const kmc_ctx* c) {
     g.spill_lo = c->sk_spill_lo;
     g.spill_cnt = c->sk_spill_cnt;
     g.spill_cap = c->sk_spill_cap;
-    g.occ_list = nullptr;
-    g.occ_list_cap = 0;
+    g.occ_list = c->sk_occ;
+    g.occ_list_cap = c->sk_occ ? c->sk.cap : 0;
     return g;
 }
 
@@ -286,6 +287,7 @@ int sk_ensure(kmc_ctx* c) {
     HIPCHK(c, hipMalloc((void**)&c->sk_spill_hi, c->sk_spill_cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk_spill_lo, c->sk_spill_cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk_spill_cnt, c->sk_spill_cap * sizeof(u64)));
+    HIPCHK(c, hipMalloc((void**)&c->sk_occ, cap * sizeof(u64)));
     return sk_clear(c);
 }
 
@@ -479,98 +481,6 @@ int launch_extract(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64
     return KMC_OK;
 }
 
-template <typename K, typename V>
-int sort_pairs_kv(kmc_ctx* c, const K* kin, K* kout, const V* vin, V* vout, u64 n, unsigned bits) {
-    size_t tmp = 0;
-    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, (size_t)n, 0u, bits, c->stream));
-    int rc = ensure(c, c->sort_tmp, tmp);
-    if (rc) return rc;
-    HIPCHK(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, kin, kout, vin, vout, (size_t)n, 0u, bits, c->stream));
-    return KMC_OK;
-}
-
-int sort_keys_k(kmc_ctx* c, const u64* kin, u64* kout, u64 n, unsigned bits) {
-    size_t tmp = 0;
-    HIPCHK(c, rocprim::radix_sort_keys(nullptr, tmp, kin, kout, (size_t)n, 0u, bits, c->stream));
-    int rc = ensure(c, c->sort_tmp, tmp);
-    if (rc) return rc;
-    HIPCHK(c, rocprim::radix_sort_keys(c->sort_tmp.p, tmp, kin, kout, (size_t)n, 0u, bits, c->stream));
-    return KMC_OK;
-}
-
-// Collapse n sorted keys (hi may be null for one-word keys) into runs.  cnt_in == nullptr: run
-// length is the count (fresh occurrences); otherwise the counts of equal keys are summed
-// (merging already counted pairs).  A trailing all-ones run (positions without a valid window) is
-// dropped when drop_sentinel is set.  The result is appended to c->runs (exact-size buffers).
-int collapse_runs(kmc_ctx* c, const u64* hi, const u64* lo, const u64* cnt_in, u64 n, bool drop_sentinel) {
-    if (!n) return KMC_OK;
-    if (n >= (1ull << 32)) return fail(c, KMC_ERR_ARG, "collapse_runs: more than 2^32-1 elements in one pass");
-    int rc = ensure(c, c->s_flags, (size_t)n * sizeof(u32));
-    if (rc) return rc;
-    rc = ensure(c, c->s_pos, (size_t)n * sizeof(u32));
-    if (rc) return rc;
-    u32* flags = (u32*)c->s_flags.p;
-    u32* pos = (u32*)c->s_pos.p;
-    const int g = grid_for(c, n, 256);
-    if (c->KW == 1) hipLaunchKernelGGL(kmc_run_flags_kernel<1>, dim3(g), dim3(256), 0, c->stream, hi, lo, n, flags);
-    else hipLaunchKernelGGL(kmc_run_flags_kernel<2>, dim3(g), dim3(256), 0, c->stream, hi, lo, n, flags);
-    HIPCHK(c, hipGetLastError());
-    size_t tmp = 0;
-    HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp, flags, pos, 0u, (size_t)n, rocprim::plus<u32>(), c->stream));
-    rc = ensure(c, c->sort_tmp, tmp);
-    if (rc) return rc;
-    HIPCHK(c, rocprim::exclusive_scan(c->sort_tmp.p, tmp, flags, pos, 0u, (size_t)n, rocprim::plus<u32>(), c->stream));
-    u32 last_pos = 0, last_flag = 0;
-    u64 last_lo = 0, last_hi = 0;
-    HIPCHK(c, hipMemcpyAsync(&last_pos, pos + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&last_flag, flags + (n - 1), sizeof(u32), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&last_lo, lo + (n - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    if (hi) HIPCHK(c, hipMemcpyAsync(&last_hi, hi + (n - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    const u64 n_runs = (u64)last_pos + last_flag;
-    const bool last_is_sentinel = drop_sentinel && (c->KW == 2 ? last_hi == ~0ull : last_lo == ~0ull);
-    const u64 keep = n_runs - (last_is_sentinel ? 1 : 0);
-    kmc_ctx::Run run;
-    rc = take_run(c, std::max<u64>(n_runs, 1), &run);
-    if (rc) return rc;
-    run.n = keep;
-    c->runs.push_back(run);  // owned from here on (returned to the pool by free_runs even if a later step fails)
-    rc = ensure(c, c->s_head, (size_t)(n_runs + 1) * sizeof(u64));
-    if (rc) return rc;
-    u64* head = (u64*)c->s_head.p;
-    if (c->KW == 1) hipLaunchKernelGGL(kmc_run_heads_kernel<1>, dim3(g), dim3(256), 0, c->stream, hi, lo, n, flags, pos, run.hi, run.lo, head);
-    else hipLaunchKernelGGL(kmc_run_heads_kernel<2>, dim3(g), dim3(256), 0, c->stream, hi, lo, n, flags, pos, run.hi, run.lo, head);
-    if (cnt_in) {
-        HIPCHK(c, hipMemsetAsync(run.cnt, 0, std::max<u64>(n_runs, 1) * sizeof(u64), c->stream));
-        hipLaunchKernelGGL(kmc_run_sums_kernel, dim3(g), dim3(256), 0, c->stream, flags, pos, cnt_in, n, run.cnt);
-    } else {
-        hipLaunchKernelGGL(kmc_run_lengths_kernel, dim3(grid_for(c, n_runs, 256)), dim3(256), 0, c->stream, head, n_runs, n, run.cnt);
-    }
-    HIPCHK(c, hipGetLastError());
-    if (!keep) {  // nothing valid in this pass: drop the empty run again
-        c->run_pool.push_back(c->runs.back());
-        c->runs.pop_back();
-    }
-    return KMC_OK;
-}
-
-// Sort n keys held in c->s_lo[0] (and c->s_hi[0]); returns the index (0/1) of the buffers holding the result.
-int sort_keys_buffers(kmc_ctx* c, u64 n, int* where) {
-    const unsigned kb = 2u * (unsigned)c->klen;
-    if (c->KW == 1) {
-        // two bits above the key so that the all-ones filler sorts strictly last
-        int rc = sort_keys_k(c, (const u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p, n, std::min(64u, kb + 2u));
-        *where = 1;
-        return rc;
-    }
-    // LSD over two words: by lo carrying hi, then (stable) by all of hi carrying lo
-    int rc = sort_pairs_kv<u64, u64>(c, (const u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p, (const u64*)c->s_hi[0].p, (u64*)c->s_hi[1].p, n, 64u);
-    if (rc) return rc;
-    rc = sort_pairs_kv<u64, u64>(c, (const u64*)c->s_hi[1].p, (u64*)c->s_hi[0].p, (const u64*)c->s_lo[1].p, (u64*)c->s_lo[0].p, n, 64u);
-    *where = 0;
-    return rc;
-}
-
 // ---- hand-written MSD radix sort + run-length (kmc_msd.cuh) ------------------------------------------
 // Sorts the n keys in lo[0] (hi[0] for two-word keys; w[0] = weights to sum, or null: every key counts
 // once), dropping all-ones filler keys, and appends the resulting sorted (key, count) run to c->runs.
@@ -676,7 +586,7 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
         if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_msd_leaf_kernel<KWV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdLeafLds<KWV, WV>)); attr = true; } \
         hipLaunchKernelGGL((kmc_msd_leaf_kernel<KWV, WV>), dim3(n_term), dim3(KMC_MSD_THREADS), sizeof(MsdLeafLds<KWV, WV>), c->stream,           \
                            (const u64*)hi[0], (const u64*)lo[0], (const u64*)(weights ? w[0] : nullptr), (const u64*)hi[1], (const u64*)lo[1], (const u64*)(weights ? w[1] : nullptr), \
-                           (const MsdTerm*)c->m_ord.p, n_term, (int)kb, hi[0], lo[0], hi[1], lo[1], t_cnt0, (u32*)c->m_nd.p); \
+                           (const MsdTerm*)c->m_ord.p, n_term, (int)kb, hi[0], lo[0], hi[1], lo[1], t_cnt0, (u32*)c->m_nd.p, ctl); \
     } while (0)
     if (KW == 1) { if (weights) MSD_LEAF(1, true); else MSD_LEAF(1, false); }
     else { if (weights) MSD_LEAF(2, true); else MSD_LEAF(2, false); }
@@ -695,8 +605,8 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     rc = take_run(c, std::max<u64>(n_pairs, 1), &run);
     if (rc) return rc;
     run.n = n_pairs;
-    run.total = c->h_ctl->n_valid;      // every valid key counts once (no weights): the run's counts sum to this
-    run.total_known = !weights;
+    run.total = weights ? (u64)c->h_ctl->w_total : (u64)c->h_ctl->n_valid;  // what the run's counts sum to
+    run.total_known = true;
     c->runs.push_back(run);
     if (KW == 1) hipLaunchKernelGGL(kmc_msd_gather_kernel<1>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, (const u32*)c->m_nd.p, (const u32*)c->m_base.p,
                                     (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1], (const u64*)t_cnt0, run.hi, run.lo, run.cnt);
@@ -824,27 +734,32 @@ int recover_overflow(kmc_ctx* c) {
 
 // pieces of at most KMC_WALK_MAX_READ bases for a batch with longer reads (kmc_walk.cuh): vr_reads = [starts | ends]
 int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
-    int rc = ensure(c, c->vr_cnt, (size_t)n_reads * sizeof(u64));
+    // pieces per read (u32), their exclusive prefix (the three-kernel scan of kmc_msd.cuh), then the pieces
+    if (n_reads >= (1ull << 32)) return fail(c, KMC_ERR_ARG, "batch too large for one walk pass");
+    const u32 nb = (u32)((n_reads + KMC_SCAN_PER_BLOCK - 1) / KMC_SCAN_PER_BLOCK);
+    int rc = ensure(c, c->vr_cnt, (size_t)n_reads * sizeof(u32));
     if (rc) return rc;
-    rc = ensure(c, c->vr_pos, (size_t)n_reads * sizeof(u64));
+    rc = ensure(c, c->vr_pos, (size_t)n_reads * sizeof(u32));
     if (rc) return rc;
-    u64 *cnt = (u64*)c->vr_cnt.p, *pos = (u64*)c->vr_pos.p;
+    rc = ensure(c, c->m_bsum, (size_t)(nb + 2) * sizeof(u32));
+    if (rc) return rc;
+    rc = ensure(c, c->m_ctl, sizeof(MsdCtl));
+    if (rc) return rc;
+    if (!c->h_ctl) HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, sizeof(MsdCtl)));
+    MsdCtl* ctl = (MsdCtl*)c->m_ctl.p;
+    u32 *cnt = (u32*)c->vr_cnt.p, *pos = (u32*)c->vr_pos.p;
     hipLaunchKernelGGL(kmc_vreads_count_kernel, dim3(grid_for(c, n_reads, 256)), dim3(256), 0, c->stream, d_offsets, n_reads, c->cfg.k, cnt);
+    hipLaunchKernelGGL(kmc_scan_sums_kernel<0>, dim3(nb), dim3(256), 0, c->stream, (const void*)cnt, (u32)n_reads, (u32*)c->m_bsum.p);
+    hipLaunchKernelGGL(kmc_scan_top_kernel, dim3(1), dim3(1024), 0, c->stream, (u32*)c->m_bsum.p, nb, &ctl->scan_total);
+    hipLaunchKernelGGL(kmc_scan_final_kernel<0>, dim3(nb), dim3(256), 0, c->stream, (const void*)cnt, (u32)n_reads, (const u32*)c->m_bsum.p, pos);
     HIPCHK(c, hipGetLastError());
-    size_t tmp = 0;
-    HIPCHK(c, rocprim::exclusive_scan(nullptr, tmp, cnt, pos, (u64)0, (size_t)n_reads, rocprim::plus<u64>(), c->stream));
-    rc = ensure(c, c->sort_tmp, tmp);
-    if (rc) return rc;
-    HIPCHK(c, rocprim::exclusive_scan(c->sort_tmp.p, tmp, cnt, pos, (u64)0, (size_t)n_reads, rocprim::plus<u64>(), c->stream));
-    u64 last_pos = 0, last_cnt = 0;
-    HIPCHK(c, hipMemcpyAsync(&last_pos, pos + (n_reads - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(&last_cnt, cnt + (n_reads - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(MsdCtl), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const u64 n_v = last_pos + last_cnt;
+    const u64 n_v = c->h_ctl->scan_total;
     rc = ensure(c, c->vr_reads, (size_t)n_v * 2 * sizeof(u64));
     if (rc) return rc;
     u64* vs = (u64*)c->vr_reads.p;
-    hipLaunchKernelGGL(kmc_vreads_fill_kernel, dim3(grid_for(c, n_v, 256)), dim3(256), 0, c->stream, d_offsets, (const u64*)pos, n_reads, n_v, c->cfg.k, vs, vs + n_v);
+    hipLaunchKernelGGL(kmc_vreads_fill_kernel, dim3(grid_for(c, n_v, 256)), dim3(256), 0, c->stream, d_offsets, (const u32*)pos, n_reads, n_v, c->cfg.k, vs, vs + n_v);
     HIPCHK(c, hipGetLastError());
     *n_v_out = n_v;
     return KMC_OK;
@@ -1026,8 +941,11 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                     rc = observe(occ, take, kpt);
                     if (rc) return rc;
                     if (c->recovered) break;  // (the sort path has counted the rest of the batch)
-                    if (c->cfg.algo == KMC_ALGO_AUTO && c->walk_overflowed) {
-                        // the memo does not help on this input (almost every k-mer is new): hand the rest
+                    if (c->cfg.algo == KMC_ALGO_AUTO && (c->walk_overflowed || (c->rho_last > 0.2 && (take >= 2048 || done * 2 >= n_tiles)))) {
+                        // (the new-key rate only counts once a launch was large or half the batch is through: the
+                        // first tiles of ANY input are all new)
+                        // the memos do not help on this input (both levels overflow, or more than one k-mer in
+                        // five is new: per-occurrence table updates are the wrong tool): hand the rest
                         // of the batch to the sort path
                         // ... from the end of the last piece walked: the windows ENDING before it are counted
                         u64 pos = 0;
@@ -1101,16 +1019,6 @@ void harvest_timing(kmc_ctx* c) {
     c->timed = false;
 }
 
-template <typename K>
-int sort_pairs(kmc_ctx* c, const K* kin, K* kout, const u64* vin, u64* vout, u64 n, unsigned bits) {
-    size_t tmp = 0;
-    HIPCHK(c, rocprim::radix_sort_pairs(nullptr, tmp, kin, kout, vin, vout, (size_t)n, 0u, bits, c->stream));
-    int rc = ensure(c, c->sort_tmp, tmp);
-    if (rc) return rc;
-    HIPCHK(c, rocprim::radix_sort_pairs(c->sort_tmp.p, tmp, kin, kout, vin, vout, (size_t)n, 0u, bits, c->stream));
-    return KMC_OK;
-}
-
 }  // namespace
 
 // ---- ABI -------------------------------------------------------------------------------------
@@ -1148,8 +1056,8 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     if (c->spill_lo) (void)hipFree(c->spill_lo);
     if (c->spill_cnt) (void)hipFree(c->spill_cnt);
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
-                      &c->t_idx0, &c->t_idx1, &c->t_key, &c->sort_tmp, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo, &c->vr_reads, &c->vr_cnt, &c->vr_pos,
-                      &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->s_flags, &c->s_pos, &c->s_head,
+                      &c->t_idx0, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo, &c->vr_reads, &c->vr_cnt, &c->vr_pos,
+                      &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1],
                       &c->m_hist, &c->m_stot, &c->m_bsum, &c->m_rmin, &c->m_rmax, &c->m_seg[0], &c->m_seg[1], &c->m_first, &c->m_cbase, &c->m_skip, &c->m_term, &c->m_ord,
                       &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_cnt, &c->m_w[0], &c->m_w[1],
                       &c->snap_hi, &c->snap_lo, &c->snap_cnt, &c->snap_n, &c->snap_occ};
@@ -1160,6 +1068,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     if (c->sk_spill_hi) (void)hipFree(c->sk_spill_hi);
     if (c->sk_spill_lo) (void)hipFree(c->sk_spill_lo);
     if (c->sk_spill_cnt) (void)hipFree(c->sk_spill_cnt);
+    if (c->sk_occ) (void)hipFree(c->sk_occ);
     try { free_runs(c, true); } catch (...) { /* (only the pool bookkeeping can throw; the buffers it could not list leak with the process) */ }
     for (DevBuf* b : bufs) free_buf(*b);
     for (hipEvent_t e : c->lev) (void)hipEventDestroy(e);
@@ -1311,29 +1220,6 @@ static int kmc_merge_pairs_device_impl(kmc_ctx* c, const void* d_key_hi, const v
     return KMC_OK;
 }
 
-// sort n compacted (hi, lo, cnt) triples held in t_* into o_* (duplicates, if any, stay adjacent)
-static int sort_view(kmc_ctx* c, u64 n) {
-    int rc;
-    const int g2 = grid_for(c, n, 256);
-    const unsigned kb = 2u * (unsigned)c->klen;
-    if (c->KW == 1) {
-        rc = sort_pairs<u64>(c, (const u64*)c->t_lo.p, (u64*)c->o_lo.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, std::max(kb, 1u));
-        if (rc) return rc;
-        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_cnt.p, (const u64*)c->t_idx1.p, (u64*)c->o_cnt.p, n);
-    } else {
-        // LSD over two words: stable sort by lo, then by hi
-        rc = sort_pairs<u64>(c, (const u64*)c->t_lo.p, (u64*)c->t_key.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, 64u);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_hi.p, (const u64*)c->t_idx1.p, (u64*)c->t_key.p, n);
-        rc = sort_pairs<u64>(c, (const u64*)c->t_key.p, (u64*)c->o_hi.p, (const u64*)c->t_idx1.p, (u64*)c->t_idx0.p, n, kb > 64 ? kb - 64 : 1u);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_lo.p, (const u64*)c->t_idx0.p, (u64*)c->o_lo.p, n);
-        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, (const u64*)c->t_cnt.p, (const u64*)c->t_idx0.p, (u64*)c->o_cnt.p, n);
-    }
-    HIPCHK(c, hipGetLastError());
-    return KMC_OK;
-}
-
 static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
@@ -1361,99 +1247,62 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     u64 n = n_tab + n_runs_total;  // entries before merging duplicates across sources
     u64 n_kmers = 0;
     const bool single_run = n_tab == 0 && c->runs.size() == 1;
-    const bool lean_merge = !c->runs.empty() && c->KW == 1;  // merge by sorting (key, count) pairs directly
-    if (!single_run && !fast_done) {
-        if (!c->runs.empty()) {
-            // a merge of big runs needs room: give back the sort path's scratch and the pooled buffers
-            DevBuf* scratch[] = {&c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->s_head};
-            for (DevBuf* b : scratch) free_buf(*b);
-            for (auto& r : c->run_pool) { if (r.hi) (void)hipFree(r.hi); (void)hipFree(r.lo); (void)hipFree(r.cnt); }
-            c->run_pool.clear();
-        }
-        const size_t nb = (size_t)std::max<u64>(n, 1) * sizeof(u64);
-        DevBuf* need[] = {&c->o_lo, &c->o_cnt, &c->t_lo, &c->t_cnt};
-        for (DevBuf* b : need) { rc = ensure(c, *b, nb); if (rc) return rc; }
-        if (!lean_merge) {
-            DevBuf* need2[] = {&c->t_idx0, &c->t_idx1, &c->t_key};
-            for (DevBuf* b : need2) { rc = ensure(c, *b, nb); if (rc) return rc; }
-        } else if (n_tab) {
-            rc = ensure(c, c->t_idx0, (size_t)std::max<u64>(n_tab, 1) * sizeof(u64));  // the compaction kernel writes it
-            if (rc) return rc;
-        }
-        if (c->KW == 2) { rc = ensure(c, c->o_hi, nb); if (rc) return rc; rc = ensure(c, c->t_hi, nb); if (rc) return rc; }
-    }
+    if (c->view_run.lo) { c->view_run.n = 0; c->run_pool.push_back(c->view_run); c->view_run = kmc_ctx::Run{}; }  // the previous finalize's view
     c->v_hi = c->KW == 2 ? (const u64*)c->o_hi.p : nullptr;
     c->v_lo = (const u64*)c->o_lo.p;
     c->v_cnt = (const u64*)c->o_cnt.p;
     if (fast_done) {
-        // small table: the single-workgroup kernel already gathered, sorted and wrote the view
+        // small table: the rank-sort kernel already gathered, sorted and wrote the view
         n_kmers = c->h_counters[KMC_CTR_SUM2];
     } else if (single_run) {
-        // one sorted run and an empty table: it IS the sorted view (no copy)
+        // one sorted run and an empty table: it IS the sorted view (no copy); the sort knows its total
         auto& r = c->runs[0];
         c->v_hi = r.hi; c->v_lo = r.lo; c->v_cnt = r.cnt;
-        if (r.total_known) {
-            n_kmers = r.total;  // (the sort already knows how many keys it counted)
-        } else {
-            HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM2], 0, sizeof(u64), c->stream));
-            hipLaunchKernelGGL(kmc_sum_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, r.cnt, n, c->d_counters);
-            HIPCHK(c, hipGetLastError());
-            rc = poll(c);
-            if (rc) return rc;
-            n_kmers = c->h_counters[KMC_CTR_SUM2];
-        }
+        n_kmers = r.total;
     } else if (n) {
+        // table entries and / or several runs: ONE weighted sort merges and orders them -- the entries are
+        // concatenated as (key, count) pairs, the hand-written radix sort (kmc_msd.cuh) orders them and
+        // its run-length step sums the counts of equal keys (the grouping of main.rs:84,87 once more)
+        if (n >= (1ull << 32) - KMC_MSD_RANGE) return fail(c, KMC_ERR_ARG, "kmc_finalize: more than 2^32 table entries + run entries to merge in one pass");
+        if (!c->runs.empty()) {
+            // a merge of big runs needs room: give back the pooled buffers
+            for (auto& r : c->run_pool) { if (r.hi) (void)hipFree(r.hi); (void)hipFree(r.lo); (void)hipFree(r.cnt); }
+            c->run_pool.clear();
+        }
+        const size_t nb = (size_t)n * sizeof(u64);
+        DevBuf* need[] = {&c->o_lo, &c->o_cnt, &c->t_lo, &c->t_cnt};
+        for (DevBuf* b : need) { rc = ensure(c, *b, nb); if (rc) return rc; }
+        if (c->KW == 2) { rc = ensure(c, c->o_hi, nb); if (rc) return rc; rc = ensure(c, c->t_hi, nb); if (rc) return rc; }
         if (n_tab) {
             const int parity = c->fin_parity;
             c->fin_parity ^= 1;
             GTable g = gtable_of(c, c->tab);
             int grid = grid_for(c, c->tab.cap, 256);
-            if (c->KW == 1) hipLaunchKernelGGL(kmc_compact_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p, parity);
-            else hipLaunchKernelGGL(kmc_compact_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)c->t_hi.p, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)c->t_idx0.p, parity);
+            if (c->KW == 1) hipLaunchKernelGGL(kmc_compact_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)nullptr, parity);
+            else hipLaunchKernelGGL(kmc_compact_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64*)c->t_hi.p, (u64*)c->t_lo.p, (u64*)c->t_cnt.p, (u64*)nullptr, parity);
             HIPCHK(c, hipGetLastError());
         }
-        if (c->runs.empty()) {
-            rc = sort_view(c, n);
-            if (rc) return rc;
-            rc = poll(c);
-            if (rc) return rc;
-            n_kmers = c->h_counters[c->fin_parity ? KMC_CTR_SUM : KMC_CTR_SUM1];  // (fin_parity was flipped above)
+        u64 off = n_tab;
+        for (auto& r : c->runs) {
+            HIPCHK(c, hipMemcpyAsync((u64*)c->t_lo.p + off, r.lo, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(c, hipMemcpyAsync((u64*)c->t_cnt.p + off, r.cnt, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            if (c->KW == 2) HIPCHK(c, hipMemcpyAsync((u64*)c->t_hi.p + off, r.hi, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+            off += r.n;
+        }
+        u64* const khi[2] = {(u64*)c->t_hi.p, (u64*)c->o_hi.p};
+        u64* const klo[2] = {(u64*)c->t_lo.p, (u64*)c->o_lo.p};
+        u64* const kwt[2] = {(u64*)c->t_cnt.p, (u64*)c->o_cnt.p};
+        const size_t before = c->runs.size();
+        rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen);
+        if (rc) return rc;
+        if (c->runs.size() > before) {
+            c->view_run = c->runs.back();   // the merged view is not one of the ctx's runs (they stay as they are)
+            c->runs.pop_back();
+            n = c->view_run.n;
+            n_kmers = c->view_run.total;
+            c->v_hi = c->view_run.hi; c->v_lo = c->view_run.lo; c->v_cnt = c->view_run.cnt;
         } else {
-            // table entries + every run, concatenated, sorted, equal keys summed
-            u64 off = n_tab;
-            for (auto& r : c->runs) {
-                HIPCHK(c, hipMemcpyAsync((u64*)c->t_lo.p + off, r.lo, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-                HIPCHK(c, hipMemcpyAsync((u64*)c->t_cnt.p + off, r.cnt, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-                if (c->KW == 2) HIPCHK(c, hipMemcpyAsync((u64*)c->t_hi.p + off, r.hi, r.n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-                off += r.n;
-            }
-            if (lean_merge) {
-                rc = sort_pairs_kv<u64, u64>(c, (const u64*)c->t_lo.p, (u64*)c->o_lo.p, (const u64*)c->t_cnt.p, (u64*)c->o_cnt.p, n, std::max(2u * (unsigned)c->klen, 1u));
-            } else {
-                hipLaunchKernelGGL(kmc_iota_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, (u64*)c->t_idx0.p, n);
-                rc = sort_view(c, n);
-            }
-            if (rc) return rc;
-            const size_t before = c->runs.size();
-            rc = collapse_runs(c, c->KW == 2 ? (const u64*)c->o_hi.p : nullptr, (const u64*)c->o_lo.p, (const u64*)c->o_cnt.p, n, false);
-            if (rc) return rc;
-            if (c->runs.size() > before) {
-                kmc_ctx::Run m = c->runs.back();
-                c->runs.pop_back();
-                n = m.n;
-                HIPCHK(c, hipMemcpyAsync(c->o_lo.p, m.lo, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-                HIPCHK(c, hipMemcpyAsync(c->o_cnt.p, m.cnt, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-                if (c->KW == 2) HIPCHK(c, hipMemcpyAsync(c->o_hi.p, m.hi, n * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
-                HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_SUM2], 0, sizeof(u64), c->stream));
-                hipLaunchKernelGGL(kmc_sum_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, (const u64*)c->o_cnt.p, n, c->d_counters);
-                HIPCHK(c, hipGetLastError());
-                rc = poll(c);
-                c->run_pool.push_back(m);
-                if (rc) return rc;
-                n_kmers = c->h_counters[KMC_CTR_SUM2];
-            } else {
-                n = 0;
-            }
+            n = 0;
         }
     }
     c->n_sorted = n;
@@ -1504,32 +1353,34 @@ static int kmc_partition_device_impl(kmc_ctx* c, uint32_t n_parts, uint64_t* par
     const u64 n = c->n_sorted;
     const size_t nb = (size_t)std::max<u64>(n, 1) * sizeof(u64);
     int rc;
-    DevBuf* need[] = {&c->p_lo, &c->p_cnt, &c->t_idx0, &c->t_idx1, &c->t_key, &c->t_lo};
+    DevBuf* need[] = {&c->p_lo, &c->p_cnt};
     for (DevBuf* b : need) { rc = ensure(c, *b, nb); if (rc) return rc; }
+    rc = ensure(c, c->t_idx0, (size_t)std::max<u64>(n_parts, 1) * sizeof(u64)); if (rc) return rc;
     if (c->KW == 2) { rc = ensure(c, c->p_hi, nb); if (rc) return rc; }
-    std::vector<u64> owners((size_t)n);
+    if (n_parts > 4096) return fail(c, KMC_ERR_ARG, "kmc_partition_device: more than 4096 parts");
+    std::vector<unsigned long long> cnt((size_t)n_parts, 0ull);
+    unsigned long long* d_cnt = (unsigned long long*)c->t_idx0.p;  // (scratch: n_parts counters, then cursors)
     if (n) {
-        int g2 = grid_for(c, n, 256);
-        hipLaunchKernelGGL(kmc_owner_kernel, dim3(g2), dim3(256), 0, c->stream, c->KW == 2 ? c->v_hi : (const u64*)nullptr,
-                           c->v_lo, n, n_parts, (u64*)c->t_key.p);
-        hipLaunchKernelGGL(kmc_iota_kernel, dim3(g2), dim3(256), 0, c->stream, (u64*)c->t_idx0.p, n);
-        unsigned bits = 1;
-        while ((1ull << bits) < n_parts) bits++;
-        rc = sort_pairs<u64>(c, (const u64*)c->t_key.p, (u64*)c->t_lo.p, (const u64*)c->t_idx0.p, (u64*)c->t_idx1.p, n, bits);
-        if (rc) return rc;
-        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, c->v_lo, (const u64*)c->t_idx1.p, (u64*)c->p_lo.p, n);
-        hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, c->v_cnt, (const u64*)c->t_idx1.p, (u64*)c->p_cnt.p, n);
-        if (c->KW == 2) hipLaunchKernelGGL(kmc_gather_u64_kernel, dim3(g2), dim3(256), 0, c->stream, c->v_hi, (const u64*)c->t_idx1.p, (u64*)c->p_hi.p, n);
+        const int g2 = grid_for(c, n, 256);
+        const u64* vhi = c->KW == 2 ? c->v_hi : (const u64*)nullptr;
+        HIPCHK(c, hipMemsetAsync(d_cnt, 0, (size_t)n_parts * sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(kmc_owner_count_kernel, dim3(g2), dim3(256), (size_t)n_parts * sizeof(unsigned int), c->stream, vhi, c->v_lo, n, n_parts, d_cnt);
         HIPCHK(c, hipGetLastError());
-        HIPCHK(c, hipMemcpyAsync(owners.data(), c->t_lo.p, n * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(cnt.data(), d_cnt, (size_t)n_parts * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     u64 pos = 0;
-    for (u32 p = 0; p <= n_parts; ++p) {
-        while (pos < n && owners[(size_t)pos] < p) pos++;
-        part_begin[p] = pos;
+    std::vector<unsigned long long> cursor((size_t)n_parts);
+    for (u32 p = 0; p < n_parts; ++p) { part_begin[p] = pos; cursor[p] = pos; pos += cnt[p]; }
+    part_begin[n_parts] = pos;
+    if (n) {
+        const u64* vhi = c->KW == 2 ? c->v_hi : (const u64*)nullptr;
+        HIPCHK(c, hipMemcpyAsync(d_cnt, cursor.data(), (size_t)n_parts * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(kmc_owner_scatter_kernel, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, vhi, c->v_lo, c->v_cnt, n, n_parts, d_cnt,
+                           (u64*)c->p_hi.p, (u64*)c->p_lo.p, (u64*)c->p_cnt.p);
+        HIPCHK(c, hipGetLastError());
+        HIPCHK(c, hipStreamSynchronize(c->stream));  // (cursor[] is host memory of this call)
     }
-    part_begin[n_parts] = n;
     if (d_key_hi) *d_key_hi = c->KW == 2 ? c->p_hi.p : nullptr;
     if (d_key_lo) *d_key_lo = c->p_lo.p;
     if (d_count) *d_count = c->p_cnt.p;

@@ -37,6 +37,8 @@
 #define KMC_MSD_LEAF1 4096    // leaf capacity, one-word keys  (two LDS images of 32 KB)
 #define KMC_MSD_LEAF2 2048    // leaf capacity, two-word keys
 #define KMC_MSD_THREAD_SORT 32  // sub-buckets up to this size are insertion-sorted by one thread
+#define KMC_MSD_LEAF_NSB 1024   // sub-buckets of a leaf: three or four keys each, so the per-thread insertion sorts
+                                // (a chain of dependent LDS round trips per move) stay a handful of moves long
 
 struct MsdSeg { u32 begin, len; };
 // kind 0: leaf (sort in LDS); kind 1: all keys equal (one pair, key = first element)
@@ -52,6 +54,7 @@ struct MsdCtl {
     u32 n_pairs;     // total (key, count) pairs (written by the terminal scan)
     u32 scan_total;  // total of the last kmc_scan_* call
     u32 pad;
+    unsigned long long w_total;  // sum of all weights (weighted sorts: the merged table's total count)
 };
 
 template <int KW>
@@ -454,7 +457,9 @@ template <int KW, bool WEIGHTS> struct MsdLeafLds {
     u64 a_lo[CAP], b_lo[CAP];
     u64 a_hi[KW == 2 ? CAP : 1], b_hi[KW == 2 ? CAP : 1];
     u64 a_w[WEIGHTS ? CAP : 1], b_w[WEIGHTS ? CAP : 1];   // weights (counts) of the keys
-    u32 cnt[256], off[257];
+    u32 cnt[KMC_MSD_LEAF_NSB], off[KMC_MSD_LEAF_NSB + 1];
+    u32 big[KMC_MSD_LEAF1 / KMC_MSD_THREAD_SORT + 4];     // sub-buckets too large for one thread
+    u32 nbig;
     u32 wsum[4];
     u32 bad;                  // a sub-bucket was too large for the in-wave rank sort
     u32 n_out;
@@ -467,7 +472,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
                          const u64* __restrict__ hi1, const u64* __restrict__ lo1, const u64* __restrict__ w1,
                          const MsdTerm* __restrict__ term, u32 n_term, int kb,
                          u64* __restrict__ s_hi0, u64* __restrict__ s_lo0, u64* __restrict__ s_hi1, u64* __restrict__ s_lo1,
-                         u64* __restrict__ t_cnt, u32* __restrict__ nd) {
+                         u64* __restrict__ t_cnt, u32* __restrict__ nd, MsdCtl* __restrict__ ctl) {
     extern __shared__ __align__(16) unsigned char msd_smem[];
     MsdLeafLds<KW, WEIGHTS>& L = *reinterpret_cast<MsdLeafLds<KW, WEIGHTS>*>(msd_smem);
     const u32 t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -489,7 +494,10 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             __syncthreads();
             s = L.sx[0][0] + L.sx[1][0] + L.sx[2][0] + L.sx[3][0];
         }
-        if (tid == 0) { t_lo[T.begin] = klo[T.begin]; if (KW == 2) t_hi[T.begin] = khi[T.begin]; t_cnt[T.begin] = s; nd[t] = 1; }
+        if (tid == 0) {
+            t_lo[T.begin] = klo[T.begin]; if (KW == 2) t_hi[T.begin] = khi[T.begin]; t_cnt[T.begin] = s; nd[t] = 1;
+            if (WEIGHTS) atomicAdd(&ctl->w_total, (unsigned long long)s);
+        }
         return;
     }
     // 1. load (n <= CAP) and find the smallest and the largest key.  Sub-bucket of a key = (key - min) >> sh,
@@ -506,8 +514,8 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         if (key_less(hi, lo, mnh, mnl)) { mnh = hi; mnl = lo; }
         if (key_less(mxh, mxl, hi, lo)) { mxh = hi; mxl = lo; }
     }
-    L.cnt[tid] = 0;
-    if (tid == 0) { L.bad = 0; L.n_out = 0; }
+    for (u32 i = tid; i < KMC_MSD_LEAF_NSB; i += KMC_MSD_THREADS) L.cnt[i] = 0;
+    if (tid == 0) { L.bad = 0; L.n_out = 0; L.nbig = 0; }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const u64 oh = __shfl_xor(mnh, o), ol = __shfl_xor(mnl, o);
@@ -537,11 +545,14 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             __syncthreads();
             sw = L.sx[0][0] + L.sx[1][0] + L.sx[2][0] + L.sx[3][0];
         }
-        if (tid == 0) { t_lo[T.begin] = fl; if (KW == 2) t_hi[T.begin] = fh; t_cnt[T.begin] = sw; nd[t] = n ? 1u : 0u; }
+        if (tid == 0) {
+            t_lo[T.begin] = fl; if (KW == 2) t_hi[T.begin] = fh; t_cnt[T.begin] = sw; nd[t] = n ? 1u : 0u;
+            if (WEIGHTS) atomicAdd(&ctl->w_total, (unsigned long long)sw);
+        }
         return;
     }
-    const int shift = top >= 8 ? top - 7 : 0;
-    // sub-bucket of a key: ((key - min) >> shift), at most 255
+    const int shift = top >= 10 ? top - 9 : 0;
+    // sub-bucket of a key: ((key - min) >> shift), at most 1023
     auto bucket = [&](u64 hi, u64 lo) -> u32 {
         const u64 dl = lo - mnl;
         if (KW == 1) return (u32)(dl >> shift);
@@ -551,34 +562,41 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         return (u32)((dl >> shift) | (dh << (64 - shift)));
     };
     // 2. LDS pass: a -> b grouped by digit
-    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) atomicAdd(&L.cnt[bucket(KW == 2 ? L.a_hi[i] : 0ull, L.a_lo[i]) & 255u], 1u);
+    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) atomicAdd(&L.cnt[bucket(KW == 2 ? L.a_hi[i] : 0ull, L.a_lo[i]) & (KMC_MSD_LEAF_NSB - 1u)], 1u);
     __syncthreads();
-    {
-        const u32 mine = L.cnt[tid];
+    {   // exclusive prefix of the sub-bucket sizes: four consecutive sub-buckets per thread
+        constexpr int PT = KMC_MSD_LEAF_NSB / KMC_MSD_THREADS;
+        u32 c[PT], mine = 0;
+#pragma unroll
+        for (int e = 0; e < PT; ++e) { c[e] = L.cnt[tid * PT + e]; mine += c[e]; }
         u32 inc = mine;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
         if (lane == 63) L.wsum[wv] = inc;
         __syncthreads();
-        u32 wbase = 0;
-        for (u32 w = 0; w < wv; ++w) wbase += L.wsum[w];
-        L.off[tid] = wbase + inc - mine;
-        if (tid == 255) L.off[256] = wbase + inc;
-        __syncthreads();
-        L.cnt[tid] = L.off[tid];  // cursors
+        u32 run = inc - mine;
+        for (u32 w = 0; w < wv; ++w) run += L.wsum[w];
+#pragma unroll
+        for (int e = 0; e < PT; ++e) {
+            L.off[tid * PT + e] = run;
+            L.cnt[tid * PT + e] = run;  // cursor
+            if (c[e] > KMC_MSD_THREAD_SORT) L.big[atomicAdd(&L.nbig, 1u)] = tid * PT + e;
+            run += c[e];
+        }
+        if (tid == KMC_MSD_THREADS - 1) L.off[KMC_MSD_LEAF_NSB] = run;
         __syncthreads();
     }
     for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
         const u64 lo = L.a_lo[i], hi = KW == 2 ? L.a_hi[i] : 0ull;
-        const u32 p = atomicAdd(&L.cnt[bucket(hi, lo) & 255u], 1u);
+        const u32 p = atomicAdd(&L.cnt[bucket(hi, lo) & (KMC_MSD_LEAF_NSB - 1u)], 1u);
         L.b_lo[p] = lo;
         if (KW == 2) L.b_hi[p] = hi;
         if (WEIGHTS) L.b_w[p] = L.a_w[i];
     }
     __syncthreads();
-    // 3a. thread d insertion-sorts sub-bucket d in place (a dozen keys on average)
-    {
-        const u32 o = L.off[tid], m = L.off[tid + 1] - o;
+    // 3a. every thread insertion-sorts its four sub-buckets in place (three keys each on average)
+    for (u32 d = tid * (KMC_MSD_LEAF_NSB / KMC_MSD_THREADS); d < (tid + 1) * (KMC_MSD_LEAF_NSB / KMC_MSD_THREADS); ++d) {
+        const u32 o = L.off[d], m = L.off[d + 1] - o;
         if (m > 1 && m <= KMC_MSD_THREAD_SORT) {
             for (u32 i = 1; i < m; ++i) {
                 const u64 lo = L.b_lo[o + i], hi = KW == 2 ? L.b_hi[o + i] : 0ull;
@@ -603,9 +621,16 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     }
     __syncthreads();
     // 3b. larger sub-buckets: rank sort by a wave (all-pairs, 64 keys of the bucket at a time), b -> a -> b
-    for (u32 d = wv; d < 256; d += 4) {
+    const u32 nbig = L.nbig;
+    for (u32 bi = wv; bi < nbig; bi += 4) {
+        const u32 d = L.big[bi];
         const u32 o = L.off[d], m = L.off[d + 1] - o;
-        if (m <= KMC_MSD_THREAD_SORT) continue;
+        {   // heavily repeated keys: a sub-bucket that holds ONE key many times is sorted as it stands
+            const u64 plo = L.b_lo[o], phi = KW == 2 ? L.b_hi[o] : 0ull;
+            bool diff = false;
+            for (u32 i = lane; i < m; i += 64) diff |= L.b_lo[o + i] != plo || (KW == 2 && L.b_hi[o + i] != phi);
+            if (__builtin_amdgcn_ballot_w64(diff) == 0) continue;
+        }
         if (m > 1024) { if (lane == 0) L.bad = 1; continue; }
         for (u32 c = 0; c < m; c += 64) {          // the chunk whose keys get their positions
             const u32 i = c + lane;
@@ -679,6 +704,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     }
     // 4. run-length over the sorted image b[0..n): every head writes its (key, sum of the run's weights)
     //    pair straight to the staging arrays at its ordinal among the heads
+    u64 wtot = 0;
     for (u32 c0 = 0; c0 < n; c0 += KMC_MSD_THREADS * 4) {
         const u32 i0 = c0 + tid * 4;  // each thread owns 4 consecutive elements of this slab
         u32 nh = 0;
@@ -710,6 +736,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
                 t_lo[T.begin + pos] = L.b_lo[i];
                 if (KW == 2) t_hi[T.begin + pos] = L.b_hi[i];
                 t_cnt[T.begin + pos] = s;
+                wtot += s;
                 ++pos;
             }
         }
@@ -718,6 +745,10 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         __syncthreads();
     }
     if (tid == 0) nd[t] = L.n_out;
+    if (WEIGHTS) {
+        wtot = wave_sum_u64(wtot);
+        if (lane == 0 && wtot) atomicAdd(&ctl->w_total, (unsigned long long)wtot);
+    }
 }
 
 // dense run: terminal t's nd[t] pairs move from its span of the staging arrays to base[t]

@@ -24,7 +24,7 @@ __global__ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_
             out_lo[idx] = g.key_lo[s];
             const u64 c = g.count[s];
             out_cnt[idx] = c;
-            out_idx[idx] = idx;
+            if (out_idx) out_idx[idx] = idx;
             sum += c;
         }
     }
@@ -80,13 +80,7 @@ __global__ void kmc_merge_pairs_kernel(GTable g, const u64* hi, const u64* lo, c
     }
 }
 
-__global__ void kmc_gather_u64_kernel(const u64* src, const u64* idx, u64* dst, u64 n) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
-}
 
-__global__ void kmc_iota_kernel(u64* dst, u64 n) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) dst[i] = i;
-}
 
 // longest read of a batch -> counters[KMC_CTR_MAXLEN] (atomicMax), used when the caller of
 // kmc_add_batch_device does not know it
@@ -113,9 +107,45 @@ __host__ __device__ inline u32 kmc_owner(u64 hi, u64 lo, u32 n_parts) {
     return (u32)((z >> 32) * (u64)n_parts >> 32);
 }
 
-__global__ void kmc_owner_kernel(const u64* hi, const u64* lo, u64 n, u32 n_parts, u64* owner_out) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
-        owner_out[i] = kmc_owner(hi ? hi[i] : 0ull, lo[i], n_parts);
+
+// ---- owner partition for the all-to-all (multi-GPU reduce of large tables) --------------------------
+// part_cnt[p] = pairs whose owner is p
+__global__ void kmc_owner_count_kernel(const u64* __restrict__ hi, const u64* __restrict__ lo, u64 n, u32 n_parts, unsigned long long* __restrict__ part_cnt) {
+    extern __shared__ unsigned int oc_smem[];
+    for (u32 p = threadIdx.x; p < n_parts; p += blockDim.x) oc_smem[p] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) atomicAdd(&oc_smem[kmc_owner(hi ? hi[i] : 0ull, lo[i], n_parts)], 1u);
+    __syncthreads();
+    for (u32 p = threadIdx.x; p < n_parts; p += blockDim.x) if (oc_smem[p]) atomicAdd(&part_cnt[p], (unsigned long long)oc_smem[p]);
+}
+// pairs to their owner's span (cursor[p] starts at the span's begin); the order inside a span is
+// arbitrary (the receiver merges pairs into its table).  One global add per (wave, owner present in it).
+__global__ void kmc_owner_scatter_kernel(const u64* __restrict__ hi, const u64* __restrict__ lo, const u64* __restrict__ cnt, u64 n, u32 n_parts,
+                                         unsigned long long* __restrict__ cursor, u64* __restrict__ o_hi, u64* __restrict__ o_lo, u64* __restrict__ o_cnt) {
+    const u64 n_round = (n + 63) & ~63ull;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += (u64)gridDim.x * blockDim.x) {
+        const bool in = i < n;
+        const u32 mine = in ? kmc_owner(hi ? hi[i] : 0ull, lo[i], n_parts) : ~0u;
+        bool todo = in;
+        u64 pos = 0;
+        unsigned long long pending;
+        while ((pending = __builtin_amdgcn_ballot_w64(todo)) != 0) {
+            const u32 p = (u32)__builtin_amdgcn_readlane((int)mine, (int)__builtin_ctzll(pending));
+            const unsigned long long grp = __builtin_amdgcn_ballot_w64(todo && mine == p);
+            unsigned long long base = 0;
+            if ((threadIdx.x & 63) == (u32)__builtin_ctzll(grp)) base = atomicAdd(&cursor[p], (unsigned long long)__popcll(grp));
+            base = ((unsigned long long)(u32)__builtin_amdgcn_readlane((int)(u32)(base >> 32), (int)__builtin_ctzll(grp)) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)base, (int)__builtin_ctzll(grp));
+            if (todo && mine == p) {
+                pos = base + __builtin_amdgcn_mbcnt_hi((u32)(grp >> 32), __builtin_amdgcn_mbcnt_lo((u32)grp, 0u));
+                todo = false;
+            }
+        }
+        if (in) {
+            o_lo[pos] = lo[i];
+            o_cnt[pos] = cnt[i];
+            if (hi) o_hi[pos] = hi[i];
+        }
+    }
 }
 
 // ---- multi-GPU reduce, small tables: fixed-size slabs ------------------------------------------
@@ -180,13 +210,6 @@ __global__ void kmc_merge_slabs_kernel(GTable g, const u64* __restrict__ slabs, 
     }
 }
 
-// sum of n counts -> counters[KMC_CTR_SUM2]
-__global__ void kmc_sum_kernel(const u64* cnt, u64 n, u64* counters) {
-    u64 a = 0;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) a += cnt[i];
-    a = wave_sum_u64(a);
-    if ((threadIdx.x & 63) == 0 && a) atomicAdd((unsigned long long*)&counters[KMC_CTR_SUM2], a);
-}
 
 // Fast finalize for small tables (n <= KMC_OCC_LIST_CAP claimed slots, listed in g.occ_list): the GPU
 // form of the reference's final ordering step (k-mer-count/src/main.rs:87) for the common case of a

@@ -270,13 +270,17 @@ __device__ __forceinline__ void sk_key(WCtx ctx, u32 label, u64& hi, u64& lo) {
 template <int KW, bool CANON>
 __global__ __launch_bounds__(256)
 void kmc_sk_unfold_kernel(GTable sk, int k, GTable g) {
-    const u64 cap = sk.capmask + 1;
+    // the claimed slots are listed in sk.occ_list (every slot of the table has room in the list), so the
+    // work is proportional to the (k+16)-mers the input really has -- none at all for the benchmark input
+    const u64 n_occ = min(sk.counters[KMC_CTR_OCCUPIED], sk.occ_list_cap);
+    const u64 n_spill = min(sk.counters[KMC_CTR_SPILL], sk.spill_cap);
+    if (n_occ == 0 && n_spill == 0) return;
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
-    // item = (slot, j): the k-mer that ends j bases before the end of the (k+16)-mer, j = 0..15
-    for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < cap * 16; w += (u64)gridDim.x * blockDim.x) {
-        const u64 slot = w >> 4;
+    // item = (entry, j): the k-mer that ends j bases before the end of the (k+16)-mer, j = 0..15
+    for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_occ * 16; w += (u64)gridDim.x * blockDim.x) {
+        const u64 slot = sk.occ_list[w >> 4];
         const u32 j = (u32)w & 15u;
         const u64 c = sk.count[slot];
         if (c) {
@@ -287,12 +291,11 @@ void kmc_sk_unfold_kernel(GTable sk, int k, GTable g) {
             km.hi = KW == 2 ? ((hi >> sh) & mask_hi) : 0ull;
             walk_gadd<KW, CANON>(g, km, k, c);
         }
-        // the 16 items of a slot sit in 16 consecutive lanes: all have read the count before lane j == 0 clears it
+        // the 16 items of an entry sit in 16 consecutive lanes: all have read the count before lane j == 0 clears it
         __builtin_amdgcn_wave_barrier();
         if (c && j == 0) sk.count[slot] = 0;
     }
     // (k+16)-mers that found no slot within the probe budget wait in the table's spill area
-    const u64 n_spill = min(sk.counters[KMC_CTR_SPILL], sk.spill_cap);
     for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_spill * 16; w += (u64)gridDim.x * blockDim.x) {
         const u64 e = w >> 4;
         const u32 sh = 2 * ((u32)w & 15u);
@@ -877,12 +880,14 @@ __host__ __device__ inline void kmc_vread_span(u64 a, u64 e, int k, u64 j, u64* 
     *st = a + j * S;
     *en = (e - *st > KMC_WALK_MAX_READ) ? *st + KMC_WALK_MAX_READ : e;
 }
-__global__ void kmc_vreads_count_kernel(const u64* __restrict__ offsets, u64 n_reads, int k, u64* __restrict__ cnt) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += (u64)gridDim.x * blockDim.x)
-        cnt[i] = kmc_vreads_of(offsets[i + 1] - offsets[i], k);
+__global__ void kmc_vreads_count_kernel(const u64* __restrict__ offsets, u64 n_reads, int k, u32* __restrict__ cnt) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_reads; i += (u64)gridDim.x * blockDim.x) {
+        const u64 v = kmc_vreads_of(offsets[i + 1] - offsets[i], k);
+        cnt[i] = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)v;  // (a batch with 2^32 pieces is refused by the caller)
+    }
 }
 // pos = exclusive scan of cnt; piece v belongs to the read i with pos[i] <= v < pos[i+1] (every read has >= 1 piece)
-__global__ void kmc_vreads_fill_kernel(const u64* __restrict__ offsets, const u64* __restrict__ pos, u64 n_reads, u64 n_v, int k,
+__global__ void kmc_vreads_fill_kernel(const u64* __restrict__ offsets, const u32* __restrict__ pos, u64 n_reads, u64 n_v, int k,
                                        u64* __restrict__ vstart, u64* __restrict__ vend) {
     for (u64 v = (u64)blockIdx.x * blockDim.x + threadIdx.x; v < n_v; v += (u64)gridDim.x * blockDim.x) {
         u64 lo = 0, hi = n_reads;  // last i with pos[i] <= v
@@ -914,9 +919,7 @@ static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const u
         hipLaunchKernelGGL((kmc_walk_unfold_kernel<KW, CANON>), dim3((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE / 256), dim3(256), 0, st,
                            (const WalkMemoSlot<KW>*)&slots[parity], gcnt, hdr, k, g);
         if (sk.key_lo) {
-            const u64 items = (sk.capmask + 1) * 16;
-            const u64 blocks = (items + 255) / 256;
-            hipLaunchKernelGGL((kmc_sk_unfold_kernel<KW, CANON>), dim3((unsigned)(blocks < (u64)n_cu * 16 ? blocks : (u64)n_cu * 16)), dim3(256), 0, st, sk, k, g);
+            hipLaunchKernelGGL((kmc_sk_unfold_kernel<KW, CANON>), dim3((unsigned)n_cu * 8), dim3(256), 0, st, sk, k, g);
             hipLaunchKernelGGL(kmc_sk_spill_reset_kernel, dim3(1), dim3(64), 0, st, sk);
         }
     }

@@ -64,13 +64,13 @@ def _worker(rank, port, k, tmpdir):
         dist.destroy_process_group()
 
 
-def _worker_reduce(rank, port, k, slab_entries, tmpdir):
+def _worker_reduce(rank, port, k, slab_entries, tmpdir, world=WORLD):
     """distributed.reduce_tables itself (slab all-gather, and the all-to-all behind it when a table
     does not fit its slab), the two ctxs replaced by the numpy stand-in of tests/slab_np.py."""
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(WORLD))
-    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         kd = importlib.import_module("k-mer-count_amd.distributed")
         import oracle_py
@@ -79,7 +79,11 @@ def _worker_reduce(rank, port, k, slab_entries, tmpdir):
         n_reads = len(offs) - 1
         # uneven shards, so that with a small slab only ONE rank is oversize (mixed case)
         cut = 2  # (2 records: at most 2 x 370 distinct 31-mers)
-        first, cnt = (0, cut) if rank == 0 else (cut, n_reads - cut)
+        if world == 2:
+            first, cnt = (0, cut) if rank == 0 else (cut, n_reads - cut)
+        else:  # rank 0: 2 records, rank 1: 3 records, the last rank: everything else (the oversize one)
+            bounds = [0, cut, cut + 3] + [n_reads] * (world - 2)
+            first, cnt = bounds[rank], bounds[rank + 1] - bounds[rank]
         sb = bases[int(offs[first]):int(offs[first + cnt])]
         so = offs[first:first + cnt + 1] - offs[first]
         local = slab_np.CpuCtx(k, oracle_py.count_kmers(sb, so, k, True))
@@ -87,7 +91,7 @@ def _worker_reduce(rank, port, k, slab_entries, tmpdir):
         sent, got = kd.reduce_tables(local, owner, slab_entries=slab_entries)
         nd, nt = owner.finalize()
         assert got == nd and sent == len(local.lo)
-        assert np.all(kd.owner_np(owner.hi, owner.lo, WORLD) == rank)
+        assert np.all(kd.owner_np(owner.hi, owner.lo, world) == rank)
         np.savez(os.path.join(tmpdir, f"owned{rank}.npz"), hi=owner.hi, lo=owner.lo, cnt=owner.cnt,
                  skipped=owner.stats().n_slabs_skipped, n_local=len(local.lo))
         dist.barrier()
@@ -138,3 +142,22 @@ def test_shard_range_covers_everything():
             assert spans[0][0] == 0 and sum(c for _, c in spans) == n
             assert all(spans[i][0] + spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(c for _, c in spans) - min(c for _, c in spans) <= 1
+
+
+@pytest.mark.parametrize("k,slab_entries,n_over_want", [(63, 3000, 1), (31, 8192, 0), (63, 8, 3)])
+def test_world3_reduce_tables_two_word_keys_and_one_oversize_rank(oracle, tmp_path, k, slab_entries, n_over_want):
+    """Three ranks (an odd world size: owner = mix(key) * 3 >> 32), two-word keys, uneven shards of which
+    exactly one does not fit its slab (k=63, 3000 entries): the two small tables travel in the all-gather,
+    the large one by the owner-partitioned all-to-all in which every rank takes part."""
+    world = 3
+    port = 33000 + (os.getpid() + 11 * k + slab_entries) % 2000
+    mp.spawn(_worker_reduce, args=(port, k, slab_entries, str(tmp_path), world), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"owned{r}.npz") for r in range(world)]
+    import slab_np
+    hi, lo, cnt = slab_np.merge_sorted([p["hi"] for p in parts], [p["lo"] for p in parts], [p["cnt"] for p in parts])
+    bases, offs = oracle.parse_fasta(SAMPLE)
+    want = oracle.count_kmers(bases, offs, k, True)
+    assert np.array_equal(hi, want.key_hi) and np.array_equal(lo, want.key_lo) and np.array_equal(cnt, want.count)
+    assert sum(len(p["lo"]) for p in parts) == want.n_distinct  # owners are disjoint
+    n_over = sum(1 for p in parts if int(p["n_local"]) > slab_entries)
+    assert n_over == n_over_want and all(int(p["skipped"]) == n_over for p in parts)
