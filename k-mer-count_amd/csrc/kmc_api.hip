@@ -38,7 +38,7 @@ struct DevBuf {
 };
 
 struct Table {
-    u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr;
+    u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr, *mid = nullptr;  // (mid: three-word keys of the (k+16)-mer table, k >= 48)
     u64 cap = 0;
 };
 
@@ -113,11 +113,11 @@ struct kmc_ctx {
         u64 ctr[KMC_CTR_N] = {0};     // the device counters before the launch
     } risky;
     DevBuf snap_hi, snap_lo, snap_cnt, snap_n, snap_occ;
-    // second-level memo of the walk kernel: (k+16)-mer table (kmc_walk.cuh), k <= 47
+    // second-level memo of the walk kernel: (k+16)-mer table (kmc_walk.cuh); three key words for k >= 48
     Table sk;
     u64* d_sk_counters = nullptr;
     u64* h_sk_counters = nullptr;   // pinned mirror (valid after a poll)
-    u64 *sk_spill_hi = nullptr, *sk_spill_lo = nullptr, *sk_spill_cnt = nullptr;
+    u64 *sk_spill_hi = nullptr, *sk_spill_lo = nullptr, *sk_spill_cnt = nullptr, *sk_spill_mid = nullptr;
     u64 sk_spill_cap = 0;
     u64* sk_occ = nullptr;          // list of its claimed slots (what the unfold kernel walks)
     bool recovered = false;  // the last poll found an overflow and recovered: the batch in flight is complete
@@ -163,6 +163,7 @@ void free_table(Table& t) {
     if (t.hi) (void)hipFree(t.hi);
     if (t.lo) (void)hipFree(t.lo);
     if (t.cnt) (void)hipFree(t.cnt);
+    if (t.mid) (void)hipFree(t.mid);
     t = Table{};
 }
 
@@ -230,7 +231,7 @@ int take_run(kmc_ctx* c, u64 cap, kmc_ctx::Run* out) {
 }
 
 GTable gtable_of(const kmc_ctx* c, const Table& t) {
-    GTable g;
+    GTable g{};
     g.key_hi = t.hi;
     g.key_lo = t.lo;
     g.count = t.cnt;
@@ -249,11 +250,13 @@ GTable sk_table_of(const kmc_ctx* c) {
     GTable g{};
     if (!c->sk.lo) return g;  // key_lo == nullptr: no second-level memo
     g.key_hi = c->sk.hi;
+    g.key_mid = c->sk.mid;
     g.key_lo = c->sk.lo;
     g.count = c->sk.cnt;
     g.capmask = c->sk.cap - 1;
     g.counters = c->d_sk_counters;
     g.spill_hi = c->sk_spill_hi;
+    g.spill_mid = c->sk_spill_mid;
     g.spill_lo = c->sk_spill_lo;
     g.spill_cnt = c->sk_spill_cnt;
     g.spill_cap = c->sk_spill_cap;
@@ -266,6 +269,7 @@ int sk_clear(kmc_ctx* c) {
     if (!c->sk.lo) return KMC_OK;
     HIPCHK(c, hipMemsetAsync(c->sk.hi, 0xFF, c->sk.cap * sizeof(u64), c->stream));
     HIPCHK(c, hipMemsetAsync(c->sk.lo, 0, c->sk.cap * sizeof(u64), c->stream));
+    if (c->sk.mid) HIPCHK(c, hipMemsetAsync(c->sk.mid, 0, c->sk.cap * sizeof(u64), c->stream));
     HIPCHK(c, hipMemsetAsync(c->sk.cnt, 0, c->sk.cap * sizeof(u64), c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_sk_counters, 0, KMC_CTR_N * sizeof(u64), c->stream));
     memset(c->h_sk_counters, 0, KMC_CTR_N * sizeof(u64));
@@ -274,19 +278,22 @@ int sk_clear(kmc_ctx* c) {
 
 // the walk kernel's (k+16)-mer table: allocated at the first walk launch of a ctx with k <= 47
 int sk_ensure(kmc_ctx* c) {
-    if (c->sk.lo || c->cfg.mode != KMC_MODE_CONTIG || c->cfg.k > KMC_SK_MAX_K) return KMC_OK;
+    if (c->sk.lo || c->cfg.mode != KMC_MODE_CONTIG) return KMC_OK;
+    const bool three = c->cfg.k > KMC_SK_MAX_K;  // a (k+16)-mer of more than 63 bases: three key words
     u64 cap = 1ull << 24;
     if (const char* e = getenv("KMC_SK_SLOTS")) { u64 v = strtoull(e, nullptr, 10); if (v >= 1024) { cap = 1; while (cap < v) cap <<= 1; } }
     c->sk.cap = cap;
     HIPCHK(c, hipMalloc((void**)&c->sk.hi, cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk.lo, cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk.cnt, cap * sizeof(u64)));
+    if (three) HIPCHK(c, hipMalloc((void**)&c->sk.mid, cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->d_sk_counters, KMC_CTR_N * sizeof(u64)));
     HIPCHK(c, hipHostMalloc((void**)&c->h_sk_counters, KMC_CTR_N * sizeof(u64)));
     c->sk_spill_cap = std::max<u64>(cap / 64, 4096);
     HIPCHK(c, hipMalloc((void**)&c->sk_spill_hi, c->sk_spill_cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk_spill_lo, c->sk_spill_cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk_spill_cnt, c->sk_spill_cap * sizeof(u64)));
+    if (three) HIPCHK(c, hipMalloc((void**)&c->sk_spill_mid, c->sk_spill_cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk_occ, cap * sizeof(u64)));
     return sk_clear(c);
 }
@@ -917,6 +924,15 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 u64 take = plan(n_tiles - done, kpt, prev);
                 if (take > plan_safe && !arm_risky(c, d_bases, d_offsets, n_reads, n_bases, 0, done ? d_ve + (done * 64 - 1) : nullptr))
                     take = plan_safe;  // (the table cannot be saved cheaply: stay within what fits for certain)
+                // the (k+16)-mer table takes one entry per step at most: a launch that could fill it is risky too;
+                // if the count table cannot be saved, this launch runs without the second-level memo
+                GTable skt = sk_table_of(c);
+                if (skt.key_lo && !c->risky.armed) {
+                    const u64 max_adds = take * 64ull * (KMC_WALK_MAX_READ / KMC_WALK_STRIDE + 1);
+                    if ((c->h_sk_counters[KMC_CTR_OCCUPIED] + max_adds) * 4 > c->sk.cap * 3 &&
+                        !arm_risky(c, d_bases, d_offsets, n_reads, n_bases, 0, done ? d_ve + (done * 64 - 1) : nullptr))
+                        skt = GTable{};
+                }
                 if (!c->walk_ws_clean) {  // (normally the unfold kernel of the previous launch left it clean)
                     rc = kmc_walk_prepare(c->stream, c->walk_ws.p);
                     if (rc) return fail(c, rc, "walk workspace reset failed");
@@ -925,12 +941,12 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 rc = launch_begin(c);  // the event pair brackets the walk kernel alone
                 if (rc) return rc;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
-                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), sk_table_of(c), 0);
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), skt, 0);
                 if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
                 rc = launch_end(c);
                 if (rc) return rc;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
-                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), sk_table_of(c), 1);
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), skt, 1);
                 if (rc) return fail(c, rc, "scalar/unfold kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
                 c->walk_ws_clean = true;
                 c->memo_parity ^= 1;
@@ -1068,6 +1084,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     if (c->sk_spill_hi) (void)hipFree(c->sk_spill_hi);
     if (c->sk_spill_lo) (void)hipFree(c->sk_spill_lo);
     if (c->sk_spill_cnt) (void)hipFree(c->sk_spill_cnt);
+    if (c->sk_spill_mid) (void)hipFree(c->sk_spill_mid);
     if (c->sk_occ) (void)hipFree(c->sk_occ);
     try { free_runs(c, true); } catch (...) { /* (only the pool bookkeeping can throw; the buffers it could not list leak with the process) */ }
     for (DevBuf* b : bufs) free_buf(*b);

@@ -29,11 +29,13 @@ enum { KMC_CTR_OCCUPIED = 0, KMC_CTR_SPILL = 1, KMC_CTR_ERR = 2, KMC_CTR_KMERS =
 // key_lo, then release key_hi; key_hi < 2^62 so neither marker is a real key.
 struct GTable {
     u64* key_hi;
+    u64* key_mid;  // third key word (KW == 3: the walk kernel's (k+16)-mer table for k >= 48), else unused
     u64* key_lo;
     u64* count;
     u64  capmask;  // capacity - 1 (capacity is a power of two)
     u64* counters; // KMC_CTR_*
     u64* spill_hi;
+    u64* spill_mid;
     u64* spill_lo;
     u64* spill_cnt;
     u64  spill_cap;
@@ -41,7 +43,7 @@ struct GTable {
     u64  occ_list_cap;
 };
 
-#define KMC_OCC_LIST_CAP 8192
+#define KMC_OCC_LIST_CAP 32768  // claimed slots listed (small-table finalize, slab packing, cheap table snapshots)
 
 __device__ __forceinline__ u64 kmc_mix64(u64 z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -50,8 +52,9 @@ __device__ __forceinline__ u64 kmc_mix64(u64 z) {
 }
 
 template <int KW>
-__device__ __forceinline__ u64 kmc_hash_key(u64 hi, u64 lo) {
-    if (KW == 2) lo ^= kmc_mix64(hi + 0x9E3779B97F4A7C15ull);
+__device__ __forceinline__ u64 kmc_hash_key(u64 hi, u64 lo, u64 mid = 0) {
+    if (KW >= 2) lo ^= kmc_mix64(hi + 0x9E3779B97F4A7C15ull);
+    if (KW == 3) lo ^= kmc_mix64(mid + 0xD6E8FEB86659FD93ull);
     return kmc_mix64(lo);
 }
 
@@ -69,10 +72,11 @@ __device__ __forceinline__ u64 ld_relaxed(const u64* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ __forceinline__ void kmc_spill(const GTable& g, u64 hi, u64 lo, u64 cnt) {
+__device__ __forceinline__ void kmc_spill(const GTable& g, u64 hi, u64 lo, u64 cnt, u64 mid = 0) {
     u64 idx = atomicAdd((unsigned long long*)&g.counters[KMC_CTR_SPILL], 1ull);
     if (idx < g.spill_cap) {
         if (g.spill_hi) g.spill_hi[idx] = hi;
+        if (g.spill_mid) g.spill_mid[idx] = mid;
         g.spill_lo[idx] = lo;
         g.spill_cnt[idx] = cnt;
     } else {
@@ -90,8 +94,8 @@ __device__ __forceinline__ void kmc_spill(const GTable& g, u64 hi, u64 lo, u64 c
 // path off into an inner spin loop, and a lane spinning on a slot held by a masked-off lane of
 // its own wave never terminates.
 template <int KW>
-__device__ __forceinline__ void gtable_add(const GTable& g, u64 hi, u64 lo, u64 cnt) {
-    u64 h = kmc_hash_key<KW>(hi, lo) & g.capmask;
+__device__ __forceinline__ void gtable_add(const GTable& g, u64 hi, u64 lo, u64 cnt, u64 mid = 0) {
+    u64 h = kmc_hash_key<KW>(hi, lo, mid) & g.capmask;
     u64 probes = 0;
     const u64 max_probes = g.capmask < 4095 ? g.capmask + 1 : 4096;
     bool done = false;
@@ -129,6 +133,7 @@ __device__ __forceinline__ void gtable_add(const GTable& g, u64 hi, u64 lo, u64 
                     u64 old = atomicCAS((unsigned long long*)&g.key_hi[h], KMC_EMPTY64, KMC_LOCKED64);
                     if (old == KMC_EMPTY64) {
                         __hip_atomic_store(&g.key_lo[h], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (KW == 3) __hip_atomic_store(&g.key_mid[h], mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __hip_atomic_store(&g.key_hi[h], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const u64 i = atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
@@ -140,7 +145,7 @@ __device__ __forceinline__ void gtable_add(const GTable& g, u64 hi, u64 lo, u64 
                 } else if (cur == KMC_LOCKED64) {
                     // being published by another lane/wave; examine it next trip
                 } else if (cur == hi) {
-                    if (ld_relaxed(&g.key_lo[h]) == lo) {
+                    if (ld_relaxed(&g.key_lo[h]) == lo && (KW != 3 || ld_relaxed(&g.key_mid[h]) == mid)) {
                         atomicAdd((unsigned long long*)&g.count[h], cnt);
                         done = true;
                     } else {
@@ -152,7 +157,7 @@ __device__ __forceinline__ void gtable_add(const GTable& g, u64 hi, u64 lo, u64 
             }
             if (advance) {
                 h = (h + 1) & g.capmask;
-                if (++probes >= max_probes) { kmc_spill(g, hi, lo, cnt); done = true; }
+                if (++probes >= max_probes) { kmc_spill(g, hi, lo, cnt, mid); done = true; }
             }
         }
     }

@@ -29,15 +29,16 @@
 #pragma once
 #include "kmc_device.cuh"
 
-#define KMC_MSD_RANGE 16384   // keys per histogram / scatter workgroup
+#define KMC_MSD_RANGE 65536   // keys per histogram / scatter workgroup (a histogram row of 1025 counters per range)
 #define KMC_MSD_BITS 10       // digit width of a level (the last level of a key may be narrower)
 #define KMC_MSD_ND (1 << KMC_MSD_BITS)
 #define KMC_MSD_NB (KMC_MSD_ND + 1)   // digit bins + "invalid position"
 #define KMC_MSD_THREADS 256
-#define KMC_MSD_LEAF1 4096    // leaf capacity, one-word keys  (two LDS images of 32 KB)
-#define KMC_MSD_LEAF2 2048    // leaf capacity, two-word keys
+#define KMC_MSD_LEAF1 2048    // leaf capacity, one-word keys  (two LDS images of 16 KB: four leaves per CU in flight)
+#define KMC_MSD_LEAF2 1024    // leaf capacity, two-word keys
 #define KMC_MSD_THREAD_SORT 32  // sub-buckets up to this size are insertion-sorted by one thread
-#define KMC_MSD_LEAF_NSB 1024   // sub-buckets of a leaf: three or four keys each, so the per-thread insertion sorts
+#define KMC_MSD_LEAF_LOGNSB 9
+#define KMC_MSD_LEAF_NSB (1 << KMC_MSD_LEAF_LOGNSB)   // sub-buckets of a leaf: three or four keys each, so the per-thread insertion sorts
                                 // (a chain of dependent LDS round trips per move) stay a handful of moves long
 
 struct MsdSeg { u32 begin, len; };
@@ -303,38 +304,55 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
     cbase[(size_t)s * KMC_MSD_NB + KMC_MSD_ND] = 0;
     seg_skip[s] = equal ? 1u : 0u;
     if (level0) ctl->n_valid = seg[s].len - n_filler;
-    auto emit_term = [&](u32 b, u32 l, u32 kind, u32 parity) {
+    if (equal) {  // stays where it is (source buffer): one pair
         const u32 i = atomicAdd(&ctl->n_term, 1u);
         if (i < term_cap) {
-            term[i] = MsdTerm{b, l, kind, parity};
-            atomicOr(&bitmap[b >> 6], 1ull << (b & 63));
+            term[i] = MsdTerm{seg[s].begin, seg[s].len, 1u, src_parity};
+            atomicOr(&bitmap[seg[s].begin >> 6], 1ull << (seg[s].begin & 63));
         } else atomicOr(&ctl->overflow, 1u);
-    };
-    if (equal) {  // stays where it is (source buffer): one pair
-        emit_term(seg[s].begin, seg[s].len, 1u, src_parity);
         return;
     }
     // children, in position order: large ones go on to the next level (or, with no bits left, are one
     // pair each); runs of consecutive small ones are merged into leaves of at most leaf_cap keys (a
-    // leaf sorts whatever keys it holds, so it need not be a single child)
-    u32 gb = 0, gl = 0;
-    for (u32 d = 0; d < KMC_MSD_ND; ++d) {
-        const u32 m = tot[d];
-        if (!m) continue;
-        if (m > leaf_cap) {
-            if (gl) { emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u); gl = 0; }
-            if (last_level) emit_term(cb_s[d], m, 1u, src_parity ^ 1u);
-            else {
-                const u32 i = atomicAdd(&ctl->n_next, 1u);
-                if (i < next_cap) next[i] = MsdSeg{cb_s[d], m}; else atomicOr(&ctl->overflow, 2u);
+    // leaf sorts whatever keys it holds, so it need not be a single child).  Two passes over the 1024
+    // totals: count what will be emitted, reserve the list space with ONE returning atomic per list
+    // (a returning atomic per terminal cost 1.6 ms per level), then write.
+    u32 t_base = 0, n_base = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        u32 nt = 0, nn = 0;
+        auto emit_term = [&](u32 b, u32 l, u32 kind, u32 parity) {
+            if (pass) {
+                const u32 i = t_base + nt;
+                if (i < term_cap) {
+                    term[i] = MsdTerm{b, l, kind, parity};
+                    atomicOr(&bitmap[b >> 6], 1ull << (b & 63));
+                }
             }
-        } else {
-            if (gl && gl + m > leaf_cap) { emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u); gl = 0; }
-            if (!gl) gb = cb_s[d];
-            gl += m;
+            ++nt;
+        };
+        u32 gb = 0, gl = 0;
+        for (u32 d = 0; d < KMC_MSD_ND; ++d) {
+            const u32 m = tot[d];
+            if (!m) continue;
+            if (m > leaf_cap) {
+                if (gl) { emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u); gl = 0; }
+                if (last_level) emit_term(cb_s[d], m, 1u, src_parity ^ 1u);
+                else {
+                    if (pass && n_base + nn < next_cap) next[n_base + nn] = MsdSeg{cb_s[d], m};
+                    ++nn;
+                }
+            } else {
+                if (gl && gl + m > leaf_cap) { emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u); gl = 0; }
+                if (!gl) gb = cb_s[d];
+                gl += m;
+            }
+        }
+        if (gl) emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u);
+        if (!pass) {
+            if (nt) { t_base = atomicAdd(&ctl->n_term, nt); if (t_base + nt > term_cap) atomicOr(&ctl->overflow, 1u); }
+            if (nn) { n_base = atomicAdd(&ctl->n_next, nn); if (n_base + nn > next_cap) atomicOr(&ctl->overflow, 2u); }
         }
     }
-    if (gl) emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u);
 }
 
 // Per range: move every key (and weight) to its child's span in the other buffer.  A tile of keys is
@@ -551,8 +569,8 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         }
         return;
     }
-    const int shift = top >= 10 ? top - 9 : 0;
-    // sub-bucket of a key: ((key - min) >> shift), at most 1023
+    const int shift = top >= KMC_MSD_LEAF_LOGNSB ? top - (KMC_MSD_LEAF_LOGNSB - 1) : 0;
+    // sub-bucket of a key: ((key - min) >> shift), at most NSB - 1
     auto bucket = [&](u64 hi, u64 lo) -> u32 {
         const u64 dl = lo - mnl;
         if (KW == 1) return (u32)(dl >> shift);
@@ -702,9 +720,11 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         }
         __syncthreads();
     }
-    // 4. run-length over the sorted image b[0..n): every head writes its (key, sum of the run's weights)
-    //    pair straight to the staging arrays at its ordinal among the heads
-    u64 wtot = 0;
+    // 4. run-length over the sorted image b[0..n).  Phase 1: the position of every run head, compacted
+    //    (a_lo is free by now and holds the list); phase 2: one thread per run -- its length is the distance
+    //    to the next head (the first version let the head's thread walk its run: one thread, thousands of
+    //    dependent LDS reads for a key with thousands of copies, everybody else waiting at the barrier).
+    u32* const hidx = reinterpret_cast<u32*>(L.a_lo);
     for (u32 c0 = 0; c0 < n; c0 += KMC_MSD_THREADS * 4) {
         const u32 i0 = c0 + tid * 4;  // each thread owns 4 consecutive elements of this slab
         u32 nh = 0;
@@ -727,24 +747,23 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         for (u32 w = 0; w < wv; ++w) wbase += L.wsum[w];
         u32 pos = wbase + inc - nh;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const u32 i = i0 + e;
-            if (i < n && head[e]) {
-                u64 s = 0;
-                u32 j = i;
-                do { s += WEIGHTS ? L.b_w[j] : 1ull; ++j; } while (j < n && L.b_lo[j] == L.b_lo[i] && (KW == 1 || L.b_hi[j] == L.b_hi[i]));
-                t_lo[T.begin + pos] = L.b_lo[i];
-                if (KW == 2) t_hi[T.begin + pos] = L.b_hi[i];
-                t_cnt[T.begin + pos] = s;
-                wtot += s;
-                ++pos;
-            }
-        }
+        for (int e = 0; e < 4; ++e) if (i0 + e < n && head[e]) hidx[pos++] = i0 + e;
         __syncthreads();
         if (tid == KMC_MSD_THREADS - 1) L.n_out = pos;  // (the last thread's end = the slab's end)
         __syncthreads();
     }
-    if (tid == 0) nd[t] = L.n_out;
+    const u32 n_out = L.n_out;
+    u64 wtot = 0;
+    for (u32 r = tid; r < n_out; r += KMC_MSD_THREADS) {
+        const u32 i = hidx[r], iend = r + 1 < n_out ? hidx[r + 1] : n;
+        u64 sum = iend - i;
+        if (WEIGHTS) { sum = 0; for (u32 j = i; j < iend; ++j) sum += L.b_w[j]; }
+        t_lo[T.begin + r] = L.b_lo[i];
+        if (KW == 2) t_hi[T.begin + r] = L.b_hi[i];
+        t_cnt[T.begin + r] = sum;
+        wtot += sum;
+    }
+    if (tid == 0) nd[t] = n_out;
     if (WEIGHTS) {
         wtot = wave_sum_u64(wtot);
         if (lane == 0 && wtot) atomicAdd(&ctl->w_total, (unsigned long long)wtot);

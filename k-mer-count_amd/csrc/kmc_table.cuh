@@ -16,10 +16,18 @@ __global__ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_
         g.counters[parity ? KMC_CTR_SUM : KMC_CTR_SUM1] = 0;
     }
     u64 sum = 0;
-    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (u64)gridDim.x * blockDim.x) {
-        bool occ = (KW == 1) ? (g.key_lo[s] != KMC_EMPTY64) : (g.key_hi[s] != KMC_EMPTY64);
+    const u64 cap_round = (cap + 63) & ~63ull;  // whole waves run every trip: the slot reservation below is wave-wide
+    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap_round; s += (u64)gridDim.x * blockDim.x) {
+        const bool occ = s < cap && ((KW == 1) ? (g.key_lo[s] != KMC_EMPTY64) : (g.key_hi[s] != KMC_EMPTY64));
+        // one returning atomic per wave (not per entry: 21 M adds to ONE address took 70 ms on a 64 M-slot table)
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(occ);
+        if (m == 0) continue;
+        unsigned long long base = 0;
+        const int leader = (int)__builtin_ctzll(m);
+        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd((unsigned long long*)&g.counters[c_out], (unsigned long long)__popcll(m));
+        base = ((unsigned long long)(u32)__builtin_amdgcn_readlane((int)(u32)(base >> 32), leader) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)base, leader);
         if (occ) {
-            u64 idx = atomicAdd((unsigned long long*)&g.counters[c_out], 1ull);
+            const u64 idx = base + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
             if (KW == 2) out_hi[idx] = g.key_hi[s];
             out_lo[idx] = g.key_lo[s];
             const u64 c = g.count[s];
@@ -227,7 +235,7 @@ __global__ void kmc_merge_slabs_kernel(GTable g, const u64* __restrict__ slabs, 
 // with workgroup barriers, in LDS with wave-local passes, or in registers with wave shuffles --
 // stamps: 6 us gather, 39 us network, 9 us output; one CU's LDS pipe carries all the data movement.)
 #define KMC_FIN_CHUNK 64
-#define KMC_FIN_PER_THREAD (KMC_OCC_LIST_CAP / 1024)
+#define KMC_FIN_ROUND 8   // keys per thread and round (a round = 8192 keys of the table)
 template <int KW>
 __global__ __launch_bounds__(1024)
 void kmc_small_finalize_kernel(GTable g, u32* __restrict__ rank, u64* __restrict__ out_hi, u64* __restrict__ out_lo, u64* __restrict__ out_cnt) {
@@ -256,36 +264,36 @@ void kmc_small_finalize_kernel(GTable g, u32* __restrict__ rank, u64* __restrict
         c_lo[tid] = lo;
         if (KW == 2) c_hi[tid] = hi;
     }
-    // every key of the table: up to 8 per thread, loaded together
-    // (and its count: only the last workgroup needs them, but loading them here takes two memory
-    // round trips off the end of the kernel's dependency chain)
-    u64 klo[KMC_FIN_PER_THREAD], khi[KMC_FIN_PER_THREAD], kcnt[KMC_FIN_PER_THREAD];
-#pragma unroll
-    for (int e = 0; e < KMC_FIN_PER_THREAD; ++e) {
-        const u64 i = (u64)e * 1024 + tid;
-        klo[e] = 0; khi[e] = 0; kcnt[e] = 0;
-        if (i < n) {
-            const u64 slot = g.occ_list[i];
-            klo[e] = g.key_lo[slot];
-            if (KW == 2) khi[e] = g.key_hi[slot];
-            kcnt[e] = g.count[slot];
-        }
-    }
     __syncthreads();
-    u32 r[KMC_FIN_PER_THREAD];
+    // every key of the table against this workgroup's 64, in rounds of 8 keys per thread (the first
+    // version held all of a table of <= 8192 keys in registers; rounds lift that limit to 32768 keys:
+    // between 8 k and 32 k keys the general sort costs 0.7 ms in launches and host round trips)
+    const u32 n_rounds = (u32)((n + 1024 * KMC_FIN_ROUND - 1) / (1024 * KMC_FIN_ROUND));
+    for (u32 rd = 0; rd < n_rounds; ++rd) {
+        u64 klo[KMC_FIN_ROUND], khi[KMC_FIN_ROUND];
+        u32 r[KMC_FIN_ROUND];
 #pragma unroll
-    for (int e = 0; e < KMC_FIN_PER_THREAD; ++e) r[e] = 0;
-    for (int j = 0; j < KMC_FIN_CHUNK; ++j) {
-        const u64 cl = c_lo[j];
-        const u64 ch = KW == 2 ? c_hi[j] : 0ull;
+        for (int e = 0; e < KMC_FIN_ROUND; ++e) {
+            const u64 i = ((u64)rd * KMC_FIN_ROUND + e) * 1024 + tid;
+            klo[e] = 0; khi[e] = 0; r[e] = 0;
+            if (i < n) {
+                const u64 slot = g.occ_list[i];
+                klo[e] = g.key_lo[slot];
+                if (KW == 2) khi[e] = g.key_hi[slot];
+            }
+        }
+        for (int j = 0; j < KMC_FIN_CHUNK; ++j) {
+            const u64 cl = c_lo[j];
+            const u64 ch = KW == 2 ? c_hi[j] : 0ull;
 #pragma unroll
-        for (int e = 0; e < KMC_FIN_PER_THREAD; ++e)
-            r[e] += (KW == 2 ? (ch < khi[e] || (ch == khi[e] && cl < klo[e])) : cl < klo[e]) ? 1u : 0u;
-    }
+            for (int e = 0; e < KMC_FIN_ROUND; ++e)
+                r[e] += (KW == 2 ? (ch < khi[e] || (ch == khi[e] && cl < klo[e])) : cl < klo[e]) ? 1u : 0u;
+        }
 #pragma unroll
-    for (int e = 0; e < KMC_FIN_PER_THREAD; ++e) {
-        const u64 i = (u64)e * 1024 + tid;
-        if (i < n && r[e]) atomicAdd(&rank[i], r[e]);
+        for (int e = 0; e < KMC_FIN_ROUND; ++e) {
+            const u64 i = ((u64)rd * KMC_FIN_ROUND + e) * 1024 + tid;
+            if (i < n && r[e]) atomicAdd(&rank[i], r[e]);
+        }
     }
     // every add of this workgroup has been performed before its ticket is drawn
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -300,18 +308,15 @@ void kmc_small_finalize_kernel(GTable g, u32* __restrict__ rank, u64* __restrict
     if (!s_last) return;
     // ---- the last workgroup: scatter to sorted order ----
     u64 sum = 0;
-#pragma unroll
-    for (int e = 0; e < KMC_FIN_PER_THREAD; ++e) {
-        const u64 i = (u64)e * 1024 + tid;
-        if (i < n) {
-            const u32 pos = __hip_atomic_load(&rank[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            rank[i] = 0;
-            const u64 c = kcnt[e];
-            out_lo[pos] = klo[e];
-            if (KW == 2) out_hi[pos] = khi[e];
-            out_cnt[pos] = c;
-            sum += c;
-        }
+    for (u64 i = tid; i < n; i += 1024) {
+        const u64 slot = g.occ_list[i];
+        const u32 pos = __hip_atomic_load(&rank[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        rank[i] = 0;
+        const u64 c = g.count[slot];
+        out_lo[pos] = g.key_lo[slot];
+        if (KW == 2) out_hi[pos] = g.key_hi[slot];
+        out_cnt[pos] = c;
+        sum += c;
     }
     sum = wave_sum_u64(sum);
     if ((tid & 63) == 0) s_sum[tid >> 6] = sum;

@@ -240,7 +240,9 @@ __device__ __forceinline__ u32 walk_node(WalkLds<KW>& L, WCtx nk) {
             if (advance) {
                 h = (h + 1) & (KMC_WALK_NCAP - 1);
                 if (h == 0) h = 1;
-                if (++probes > 64) done = true;
+                // (a full table is only LOOKED UP: a key that is not within a few slots of its home is not
+                // worth a long walk -- every step that falls off a full memo used to pay up to 64 probes here)
+                if (++probes > (room ? 64 : 6)) done = true;
             }
         }
     }
@@ -252,18 +254,21 @@ __device__ __forceinline__ u32 walk_node(WalkLds<KW>& L, WCtx nk) {
 // with 16 global atomics (and KMC_ALGO_AUTO gave the input up to the sort path as soon as 5 % of the
 // k-mers went that way: a 100-400x cliff between a pool of 20 and a pool of 26 lines).  Such a step is
 // fully described by ONE (k+16)-mer -- the context followed by the 16 bases of the step -- so it is now
-// counted as one add into a second global table keyed by that (k+16)-mer (two words: k <= 47), one
-// global atomic per 16 bases; kmc_sk_unfold_kernel later gives the count to each of the (k+16)-mer's
+// counted as one add into a second global table keyed by that (k+16)-mer (two key words for k <= 47,
+// three above), one global atomic per 16 bases; kmc_sk_unfold_kernel later gives the count to each of the (k+16)-mer's
 // last 16 k-mers, once per distinct (k+16)-mer instead of once per occurrence.  Additive, so exact.
 // The table keeps its keys across launches (like the LDS memo) and is cleared by kmc_forget_source.
 #define KMC_SK_MAX_K 47
 // the (k+16)-mer of a step: context (2k bits, public code, newest base lowest) followed by the label
 // (16 bases, internal code, first base in the low bits)
-__device__ __forceinline__ void sk_key(WCtx ctx, u32 label, u64& hi, u64& lo) {
+// count one traversal of the step (ctx, label) in the (k+16)-mer table
+__device__ __forceinline__ void sk_add(const GTable& sk, WCtx ctx, u32 label) {
     const u32 pub = label ^ ((label >> 1) & 0x55555555u);  // A0 C1 T2 G3 -> A0 C1 G2 T3
     const u32 be = le_to_be(pub);                           // first base of the step in the top bits
-    hi = (ctx.hi << 32) | (ctx.lo >> 32);
-    lo = (ctx.lo << 32) | be;
+    const u64 lo = (ctx.lo << 32) | be;
+    const u64 mid = (ctx.hi << 32) | (ctx.lo >> 32);
+    if (sk.key_mid) gtable_add<3>(sk, ctx.hi >> 32, lo, 1, mid);
+    else gtable_add<2>(sk, mid, lo, 1);
 }
 
 // every (k+16)-mer with a count gives it to its last 16 k-mers; counts are cleared for the next launch
@@ -284,11 +289,13 @@ void kmc_sk_unfold_kernel(GTable sk, int k, GTable g) {
         const u32 j = (u32)w & 15u;
         const u64 c = sk.count[slot];
         if (c) {
-            const u64 hi = sk.key_hi[slot], lo = sk.key_lo[slot];
+            // (two words: {hi, lo}; three words: {top, hi = mid, lo})
+            const u64 hi = sk.key_mid ? sk.key_mid[slot] : sk.key_hi[slot], lo = sk.key_lo[slot];
+            const u64 top = sk.key_mid ? sk.key_hi[slot] : 0ull;
             const u32 sh = 2 * j;  // drop the last j bases
             WCtx km;
             km.lo = (sh ? ((lo >> sh) | (hi << (64 - sh))) : lo) & mask_lo;
-            km.hi = KW == 2 ? ((hi >> sh) & mask_hi) : 0ull;
+            km.hi = KW == 2 ? ((sh ? ((hi >> sh) | (top << (64 - sh))) : hi) & mask_hi) : 0ull;
             walk_gadd<KW, CANON>(g, km, k, c);
         }
         // the 16 items of an entry sit in 16 consecutive lanes: all have read the count before lane j == 0 clears it
@@ -299,10 +306,11 @@ void kmc_sk_unfold_kernel(GTable sk, int k, GTable g) {
     for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < n_spill * 16; w += (u64)gridDim.x * blockDim.x) {
         const u64 e = w >> 4;
         const u32 sh = 2 * ((u32)w & 15u);
-        const u64 hi = sk.spill_hi[e], lo = sk.spill_lo[e], c = sk.spill_cnt[e];
+        const u64 hi = sk.spill_mid ? sk.spill_mid[e] : sk.spill_hi[e], lo = sk.spill_lo[e], c = sk.spill_cnt[e];
+        const u64 top = sk.spill_mid ? sk.spill_hi[e] : 0ull;
         WCtx km;
         km.lo = (sh ? ((lo >> sh) | (hi << (64 - sh))) : lo) & mask_lo;
-        km.hi = KW == 2 ? ((hi >> sh) & mask_hi) : 0ull;
+        km.hi = KW == 2 ? ((sh ? ((hi >> sh) | (top << (64 - sh))) : hi) & mask_hi) : 0ull;
         if (c) walk_gadd<KW, CANON>(g, km, k, c);
     }
 }
@@ -318,9 +326,7 @@ __device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s,
     if (s == 0) {  // direct mode: no node of the LDS memo stands for this lane's context
         if (sk.key_lo && len == KMC_WALK_STRIDE && ddepth >= (u32)k) {
             // a full step from a k-mer context: one add of its (k+16)-mer (second-level memo, above)
-            u64 shi, slo;
-            sk_key(dctx, label, shi, slo);
-            gtable_add<2>(sk, shi, slo, 1);
+            sk_add(sk, dctx, label);
             (void)walk_roll<KW, CANON, false>(g, dctx, ddepth, label, len, k, mask_hi, mask_lo, 0);
         } else {
             ndirect += walk_roll<KW, CANON, true>(g, dctx, ddepth, label, len, k, mask_hi, mask_lo, 1);
@@ -390,7 +396,8 @@ __device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s,
                 }
             } else {
                 hh = (hh + 1) & (KMC_WALK_ECAP - 1);
-                if (++probes > 32) done = true;  // memo (locally) full
+                const bool eroom = __hip_atomic_load(&L.nedges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < (u32)(KMC_WALK_ECAP * 3 / 4);
+                if (++probes > (eroom ? 32 : 6)) done = true;  // memo (locally) full
             }
         }
     }
@@ -401,9 +408,7 @@ __device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s,
     u32 depth;
     node_decode<KW>(node_key_load<KW>(L, id), k, ctx, depth);
     if (sk.key_lo && len == KMC_WALK_STRIDE && depth >= (u32)k) {
-        u64 shi, slo;
-        sk_key(ctx, label, shi, slo);
-        gtable_add<2>(sk, shi, slo, 1);
+        sk_add(sk, ctx, label);
         (void)walk_roll<KW, CANON, false>(g, ctx, depth, label, len, k, mask_hi, mask_lo, 0);
     } else {
         ndirect += walk_roll<KW, CANON, true>(g, ctx, depth, label, len, k, mask_hi, mask_lo, 1);

@@ -172,7 +172,7 @@ def _all_gather_slabs(gathered: torch.Tensor, slab: torch.Tensor, group=None):
         gathered.copy_(h)
 
 
-def reduce_tables(local, owner, group=None, slab_entries: int = SLAB_ENTRIES, report_sent: bool = True):
+def reduce_tables(local, owner, group=None, slab_entries: int = SLAB_ENTRIES, report_sent: bool = True, finalize: bool = True):
     """The RCCL count-table reduce.  `local`: KmerCounter holding this rank's counts;
     `owner`: a second (reset) KmerCounter on the same GPU that receives the keys this rank owns.
     Afterwards owner.export() is this rank's partition of the global table.
@@ -185,7 +185,13 @@ def reduce_tables(local, owner, group=None, slab_entries: int = SLAB_ENTRIES, re
     whose table is too large marks its slab "oversize"; every rank sees that in the gathered
     headers (stats().n_slabs_skipped of the owner) and those tables then travel by the
     owner-partitioned all-to-all.  Returns (pairs_sent or None, pairs_owned); report_sent=False
-    skips the extra read-back of this rank's own slab header."""
+    skips the extra read-back of this rank's own slab header.
+
+    finalize=False (both ctxs on torch's current stream): nothing here waits for the GPU -- count, pack,
+    all-gather and merge are queued and the call returns (None, None).  The caller finalizes `owner`
+    when it needs the table (e.g. once after several steps) and must then check
+    owner.stats().n_slabs_skipped: a non-zero value means some rank's table did not fit its slab and
+    that step has to be redone with finalize=True (which routes those tables through the all-to-all)."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = _dev_of(local)
@@ -196,6 +202,10 @@ def reduce_tables(local, owner, group=None, slab_entries: int = SLAB_ENTRIES, re
     _all_gather_slabs(gathered, slab, group)
     _order(owner, dev, ctx_first=False)     # gathered slabs landed before the owner's stream reads them
     owner.merge_slabs_device(gathered.data_ptr(), world, slab_entries, rank, world)
+    if not finalize:
+        if dev.type == "cuda" and not (_same_stream(local, dev) and _same_stream(owner, dev)):
+            raise ValueError("reduce_tables(finalize=False) needs both ctxs on torch's current stream")
+        return None, None
     got, _ = owner.finalize()
     if local.stats().launches_last != 1:
         # `local` is never finalized on this path, so its launch planner would not learn what the

@@ -295,13 +295,13 @@ def test_device_resident_batches_and_synth(kmc, oracle):
 
 def test_small_table_finalize_sizes(kmc):
     """The rank-sort finalize of small tables at its size boundaries (64 keys per workgroup, 1024
-    threads, at most 8192 keys; 8193 takes the library sort), one- and two-word keys, repeated on the
-    same ctx (the kernel must leave its rank/ticket workspace clean)."""
+    threads, rounds of 8192 keys, at most 32768 keys; 32769 takes the weighted radix sort), one- and
+    two-word keys, repeated on the same ctx (the kernel must leave its rank/ticket workspace clean)."""
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(55)
     for k in (31, 63):
         with kmc.KmerCounter(k=k) as kc:
-            for n in (1, 2, 63, 64, 65, 127, 1023, 1024, 1025, 3350, 4096, 8191, 8192, 8193, 20000, 64):
+            for n in (1, 2, 63, 64, 65, 127, 1023, 1024, 1025, 3350, 4096, 8191, 8192, 8193, 20000, 32767, 32768, 32769, 70000, 64):
                 lo = rng.integers(0, 2**62, n, dtype=np.uint64)
                 hi = rng.integers(0, 2**60, n, dtype=np.uint64) if k > 31 else np.zeros(n, np.uint64)
                 if k > 31:
@@ -950,4 +950,32 @@ def test_wrong_prediction_is_recovered_not_fatal(kmc, oracle, algo_name):
     with kmc.KmerCounter(k=k, algo=algo) as kc:
         kc.forget_source(memo=True, history=True)
         kc.add_batch(mix_b, mix_o)
+        assert kc.export().equals(want)
+
+
+@pytest.mark.parametrize("k", [21, 31, 40, 47, 48, 63])
+def test_walk_second_level_memo_kplus16_table(kmc, oracle, k, monkeypatch):
+    """More contexts than the LDS memo holds (pools of 64 and 300 lines: thousands of nodes): full steps
+    from k-mer contexts are counted as (k+16)-mers in the second-level table (two key words for k <= 47,
+    three above) and unfolded once per launch.  Exact tables; almost nothing is counted k-mer by k-mer;
+    and with the table made tiny (KMC_SK_SLOTS) it overflows, the launch is undone and sorted instead."""
+    for pool, n_rec in ((64, 120_000), (300, 120_000)):
+        s = kmc.Synth(seed=31 + pool, pool=pool)
+        hb, ho = kmc.synth_reads_host(s, 0, n_rec)
+        want = oracle.count_kmers(hb, ho, k, True, method=1)
+        for algo in (kmc.ALGO_WALK, kmc.ALGO_AUTO):
+            with kmc.KmerCounter(k=k, algo=algo) as kc:
+                for rep in range(2):   # (the second pass runs on the learned memo + history: one launch)
+                    kc.reset()
+                    kc.add_batch(hb, ho)
+                    got = kc.export()
+                    st = kc.stats()
+                    assert got.equals(want), (k, pool, algo, rep)
+                    assert st.algo_last == kmc.ALGO_WALK and st.n_direct * 20 < want.n_total, (k, pool, algo, rep, st.n_direct)
+    monkeypatch.setenv("KMC_SK_SLOTS", "4096")
+    with kmc.KmerCounter(k=k, algo=kmc.ALGO_WALK) as kc:
+        kc.add_batch(hb, ho)
+        kc.finalize()
+        kc.reset()
+        kc.add_batch(hb, ho)          # one launch on history: the tiny table and its spill area overflow
         assert kc.export().equals(want)

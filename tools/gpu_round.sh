@@ -43,4 +43,13 @@ import json
 for l in open("gpurun_out/${tag}_pool_sweep.jsonl"):
     d=json.loads(l); print(d["k"], d["pool"], d["algo_last"], d["distinct"], "step_ms", d["step_ms"], "kern_ms", d["count_kernels_ms"], "direct", d["direct_share"], "first", d["first_step_ms"])
 P
-timeout -k 10 120 python tools/measure_lr.py > gpurun_out/${tag}_lr.txt 2>&1; echo "lr rc=$?"; tail -5 gpurun_out/${tag}_lr.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_lr -- python3 tools/measure_lr.py > gpurun_out/${tag}_lr.txt 2> gpurun_out/${tag}_lr.err; echo "lr rc=$?"
+python3 - <<P
+import json,csv,glob
+try:
+    d=json.loads(open("gpurun_out/${tag}_lr.txt").read().strip().splitlines()[-1])
+    for k,v in d.items(): print("lr", k, v["keys"], v["distinct"], "gpu_s", v["gpu_s"], "Gkeys/s", round(v["gpu_keys_per_s"]/1e9,2), v["bit_exact"])
+except Exception as e: print("lr unreadable", e)
+for f in glob.glob("gpurun_out/prof_${tag}_lr/*/*_kernel_stats.csv")[:1]:
+    for r in list(csv.DictReader(open(f)))[:10]: print(r["Name"][:52].ljust(52), r["Calls"].rjust(4), round(float(r["AverageNs"])/1e6,3), r["Percentage"])
+P
