@@ -2,7 +2,7 @@
 // scheduling, table growth, finalisation (compact + device radix sort), export.
 //
 // One ctx == one GPU.  All work is queued on the ctx stream; kernels are the hand-written
-// gfx950 kernels of kmc_stream.cuh / kmc_walk.cuh / kmc_table.cuh.  There is no CPU path: if
+// gfx950 kernels of kmc_stream.hip.h / kmc_walk.hip.h / kmc_table.hip.h.  There is no CPU path: if
 // the HIP runtime has no device, kmc_create fails.
 #include <stdarg.h>
 #include <stdio.h>
@@ -14,18 +14,21 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <climits>
+#include <thread>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/kmc.h"
-#include "kmc_device.cuh"
-#include "kmc_stream.cuh"
-#include "kmc_synth.cuh"
-#include "kmc_table.cuh"
-#include "kmc_walk.cuh"
-#include "kmc_lr.cuh"
-#include "kmc_msd.cuh"
+#include "kmc_device.hip.h"
+#include "kmc_stream.hip.h"
+#include "kmc_synth.hip.h"
+#include "kmc_table.hip.h"
+#include "kmc_walk.hip.h"
+#include "kmc_lr.hip.h"
+#include "kmc_msd.hip.h"
 #include "kmc_ingest.h"
 
 namespace {
@@ -69,12 +72,12 @@ struct kmc_ctx {
     // walk-kernel workspace
     DevBuf walk_ws;
     DevBuf vr_reads, vr_cnt, vr_pos;  // pieces of long reads for the walk kernel: [starts | ends], per-read counts and their scan
-    DevBuf walk_memo;  // two shared memo snapshots + dense counters, kept across launches (kmc_walk.cuh)
+    DevBuf walk_memo;  // two shared memo snapshots + dense counters, kept across launches (kmc_walk.hip.h)
     int memo_parity = 0;  // snapshot slot the next walk launch reads
     bool walk_ws_clean = false;  // workspace header + dense counters are zero (left so by kmc_walk_unfold_kernel)
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
     DevBuf s_lo[2], s_hi[2];
-    // hand-written MSD radix sort (kmc_msd.cuh): per-range histograms, segment lists, terminals
+    // hand-written MSD radix sort (kmc_msd.hip.h): per-range histograms, segment lists, terminals
     DevBuf m_hist, m_stot, m_bsum, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_cnt, m_w[2];
     MsdCtl* h_ctl = nullptr;  // pinned mirror of the sort's device counters
     struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0, cap = 0; u64 total = 0; bool total_known = false; };
@@ -82,7 +85,7 @@ struct kmc_ctx {
     std::vector<Run> run_pool;   // buffers of dropped runs, reused (multi-GB hipMalloc/hipFree per batch is slow)
     Run view_run;                // the merged, sorted view built by the last kmc_finalize (table entries + runs)
     const u64 *v_hi = nullptr, *v_lo = nullptr, *v_cnt = nullptr;  // the sorted view of the last finalize
-    bool prefer_sort = false;  // AUTO: the data source proved high-cardinality  // per-workgroup memo slots, kept across launches (kmc_walk.cuh)
+    bool prefer_sort = false;  // AUTO: the data source proved high-cardinality  // per-workgroup memo slots, kept across launches (kmc_walk.hip.h)
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the whole batch
     std::vector<hipEvent_t> lev;              // pairs bracketing every count-kernel launch of the batch
@@ -113,7 +116,7 @@ struct kmc_ctx {
         u64 ctr[KMC_CTR_N] = {0};     // the device counters before the launch
     } risky;
     DevBuf snap_hi, snap_lo, snap_cnt, snap_n, snap_occ;
-    // second-level memo of the walk kernel: (k+16)-mer table (kmc_walk.cuh); three key words for k >= 48
+    // second-level memo of the walk kernel: (k+16)-mer table (kmc_walk.hip.h); three key words for k >= 48
     Table sk;
     u64* d_sk_counters = nullptr;
     u64* h_sk_counters = nullptr;   // pinned mirror (valid after a poll)
@@ -121,6 +124,8 @@ struct kmc_ctx {
     u64 sk_spill_cap = 0;
     u64* sk_occ = nullptr;          // list of its claimed slots (what the unfold kernel walks)
     bool recovered = false;  // the last poll found an overflow and recovered: the batch in flight is complete
+    bool sk_dirty = false;   // walk launches since the last unfold of the (k+16)-mer table
+    DevBuf rx_hi, rx_lo, rx_cnt;  // receive buffers of the one-process multi-GPU reduce (a peer's sorted table)
 };
 
 namespace {
@@ -488,7 +493,7 @@ int launch_extract(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64
     return KMC_OK;
 }
 
-// ---- hand-written MSD radix sort + run-length (kmc_msd.cuh) ------------------------------------------
+// ---- hand-written MSD radix sort + run-length (kmc_msd.hip.h) ------------------------------------------
 // Sorts the n keys in lo[0] (hi[0] for two-word keys; w[0] = weights to sum, or null: every key counts
 // once), dropping all-ones filler keys, and appends the resulting sorted (key, count) run to c->runs.
 // lo[1] / hi[1] / w[1] are scratch of the same size.  One host synchronisation per level (the number
@@ -498,7 +503,7 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     if (n >= (1ull << 32) - KMC_MSD_RANGE) return fail(c, KMC_ERR_ARG, "msd sort: more than 2^32 keys in one pass");
     const int KW = c->KW;
     const bool weights = w[0] != nullptr;
-    const u32 leaf_cap = KW == 1 ? KMC_MSD_LEAF1 : KMC_MSD_LEAF2;
+    const u32 leaf_cap = KW == 1 ? KMC_MSD_LEAF1 : (w[0] ? KMC_MSD_LEAF2W : KMC_MSD_LEAF2);
     const u64 max_seg = n / leaf_cap + 257;
     const u64 max_ranges = n / KMC_MSD_RANGE + max_seg + 1;
     const u64 term_cap = 16 * (n / leaf_cap) + 65536;
@@ -521,48 +526,41 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     MSD_ENSURE(c->m_nd, term_cap * sizeof(u32));
     MSD_ENSURE(c->m_base, term_cap * sizeof(u32));
     MSD_ENSURE(c->m_ctl, sizeof(MsdCtl));
-    MSD_ENSURE(c->m_bsum, (std::max<u64>(n_words, term_cap) / KMC_SCAN_PER_BLOCK + 2) * sizeof(u32));
     MSD_ENSURE(c->m_cnt, n * sizeof(u64));
+    MSD_ENSURE(c->m_bsum, (std::max<u64>(n_words, term_cap) / KMC_SCAN_PER_BLOCK + 2) * sizeof(u32));
 #undef MSD_ENSURE
     if (!c->h_ctl) HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, sizeof(MsdCtl)));
     MsdCtl* ctl = (MsdCtl*)c->m_ctl.p;
     HIPCHK(c, hipMemsetAsync(ctl, 0, sizeof(MsdCtl), c->stream));
     HIPCHK(c, hipMemsetAsync(c->m_bitmap.p, 0, n_words * sizeof(u64), c->stream));
-    const MsdSeg root{0u, (u32)n};
+    const MsdSeg root{0u, (u32)n, kb, 0u};  // (in buffer 0)
     HIPCHK(c, hipMemcpyAsync(c->m_seg[0].p, &root, sizeof(root), hipMemcpyHostToDevice, c->stream));
     u32 n_seg = 1;
-    int cur = 0, par = 0;
-    const int levels = kb <= KMC_MSD_BITS ? 1 : (int)((kb + KMC_MSD_BITS - 1) / KMC_MSD_BITS);
-    for (int l = 0; l < levels && n_seg; ++l) {
-        const int hi_bit = (int)kb - KMC_MSD_BITS * l;
-        const int width = hi_bit < KMC_MSD_BITS ? hi_bit : KMC_MSD_BITS;
-        const int shift = hi_bit - width;
-        const u32 mask = (1u << width) - 1u;
-        const int last = shift == 0 ? 1 : 0;
+    int cur = 0;
+    // (every level takes at least one bit off every active segment, normally ten: kb levels at most)
+    for (int l = 0; l < (int)kb && n_seg; ++l) {
         MsdSeg* seg = (MsdSeg*)c->m_seg[cur].p;
         MsdSeg* next = (MsdSeg*)c->m_seg[cur ^ 1].p;
         u32* first = (u32*)c->m_first.p;
         hipLaunchKernelGGL(kmc_msd_ranges_kernel, dim3(1), dim3(1024), 0, c->stream, (const MsdSeg*)seg, n_seg, first, ctl);
         const u32 grid = (u32)std::min<u64>(n / KMC_MSD_RANGE + n_seg + 1, max_ranges);
-        const u64 *shi = hi[par], *slo = lo[par], *sw = weights ? w[par] : nullptr;
-        u64 *dhi = hi[par ^ 1], *dlo = lo[par ^ 1], *dw = weights ? w[par ^ 1] : nullptr;
-        if (KW == 1) hipLaunchKernelGGL(kmc_msd_hist_kernel<1>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, shi, slo, (const MsdSeg*)seg, n_seg, (const u32*)first, shift, mask, (int)kb, l == 0 ? 1 : 0,
-                                        (u32*)c->m_hist.p, (u64*)c->m_rmin.p, (u64*)c->m_rmax.p, (const MsdCtl*)ctl);
-        else hipLaunchKernelGGL(kmc_msd_hist_kernel<2>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, shi, slo, (const MsdSeg*)seg, n_seg, (const u32*)first, shift, mask, (int)kb, l == 0 ? 1 : 0,
-                                (u32*)c->m_hist.p, (u64*)c->m_rmin.p, (u64*)c->m_rmax.p, (const MsdCtl*)ctl);
+        if (KW == 1) hipLaunchKernelGGL(kmc_msd_hist_kernel<1>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1],
+                                        (const MsdSeg*)seg, n_seg, (const u32*)first, (int)kb, l == 0 ? 1 : 0, (u32*)c->m_hist.p, (u64*)c->m_rmin.p, (u64*)c->m_rmax.p, (const MsdCtl*)ctl);
+        else hipLaunchKernelGGL(kmc_msd_hist_kernel<2>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1],
+                                (const MsdSeg*)seg, n_seg, (const u32*)first, (int)kb, l == 0 ? 1 : 0, (u32*)c->m_hist.p, (u64*)c->m_rmin.p, (u64*)c->m_rmax.p, (const MsdCtl*)ctl);
         HIPCHK(c, hipMemsetAsync(&ctl->n_next, 0, sizeof(u32), c->stream));
         const u32 S = n_seg <= 4096 ? 64u : 1u;  // few segments = long ones: digit columns spread over 64 workgroups
         hipLaunchKernelGGL(kmc_msd_scan_a_kernel, dim3(n_seg * S), dim3(KMC_MSD_THREADS), 0, c->stream, n_seg, S, (const u32*)first, (u32*)c->m_hist.p, (u32*)c->m_stot.p);
-        hipLaunchKernelGGL(kmc_msd_scan_kernel, dim3(n_seg), dim3(KMC_MSD_ND), 0, c->stream, (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)c->m_stot.p,
-                           (const u64*)c->m_rmin.p, (const u64*)c->m_rmax.p, (u32*)c->m_cbase.p, (u32*)c->m_skip.p, last, l == 0 ? 1 : 0, leaf_cap, (u32)par,
+        hipLaunchKernelGGL(kmc_msd_scan_kernel, dim3(n_seg), dim3(KMC_MSD_ND), 0, c->stream, (const MsdSeg*)seg, n_seg, (const u32*)first, (u32*)c->m_hist.p, (const u32*)c->m_stot.p,
+                           (const u64*)c->m_rmin.p, (const u64*)c->m_rmax.p, (u32*)c->m_cbase.p, (u32*)c->m_skip.p, l == 0 ? 1 : 0, leaf_cap,
                            next, (u32)max_seg, (MsdTerm*)c->m_term.p, (u32)term_cap, (unsigned long long*)c->m_bitmap.p, ctl);
 #define MSD_SCATTER(KWV, WV)                                                                                                              \
         do {                                                                                                                              \
             static bool attr = false;                                                                                                     \
             if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_msd_scatter_kernel<KWV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdScatterLds<KWV, WV>)); attr = true; } \
-            hipLaunchKernelGGL((kmc_msd_scatter_kernel<KWV, WV>), dim3(grid), dim3(1024), sizeof(MsdScatterLds<KWV, WV>), c->stream, shi, slo, sw, dhi, dlo, dw, \
+            hipLaunchKernelGGL((kmc_msd_scatter_kernel<KWV, WV>), dim3(grid), dim3(1024), sizeof(MsdScatterLds<KWV, WV>), c->stream, hi[0], lo[0], w[0], hi[1], lo[1], w[1], \
                                (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)c->m_hist.p, (const u32*)c->m_cbase.p, (const u32*)c->m_skip.p, \
-                               shift, mask, (int)kb, l == 0 ? 1 : 0, (const MsdCtl*)ctl);                                                 \
+                               (int)kb, l == 0 ? 1 : 0, (const MsdCtl*)ctl);                                                 \
         } while (0)
         if (KW == 1) { if (weights) MSD_SCATTER(1, true); else MSD_SCATTER(1, false); }
         else { if (weights) MSD_SCATTER(2, true); else MSD_SCATTER(2, false); }
@@ -573,7 +571,6 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
         if (c->h_ctl->overflow) return fail(c, KMC_ERR_CAPACITY, "msd sort: segment / terminal list overflow (%u)", c->h_ctl->overflow);
         n_seg = c->h_ctl->n_next;
         cur ^= 1;
-        par ^= 1;
     }
     const u32 n_term = c->h_ctl->n_term;
     if (!n_term) return KMC_OK;  // nothing but filler
@@ -722,6 +719,7 @@ int recover_overflow(kmc_ctx* c) {
         HIPCHK(c, hipMemcpyAsync(c->d_counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, c->stream));
     }
     { int rs = sk_clear(c); if (rs) return rs; }  // (its counts belong to the launch that is being undone)
+    c->sk_dirty = false;
     u64 from = r.base_from;
     if (r.d_from) HIPCHK(c, hipMemcpyAsync(&from, r.d_from, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // (ctr[] and `from` are stack memory)
@@ -739,9 +737,9 @@ int recover_overflow(kmc_ctx* c) {
     return run_sort_path(c, r.d_bases, r.d_offsets, r.n_reads, r.n_bases, from);
 }
 
-// pieces of at most KMC_WALK_MAX_READ bases for a batch with longer reads (kmc_walk.cuh): vr_reads = [starts | ends]
+// pieces of at most KMC_WALK_MAX_READ bases for a batch with longer reads (kmc_walk.hip.h): vr_reads = [starts | ends]
 int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
-    // pieces per read (u32), their exclusive prefix (the three-kernel scan of kmc_msd.cuh), then the pieces
+    // pieces per read (u32), their exclusive prefix (the three-kernel scan of kmc_msd.hip.h), then the pieces
     if (n_reads >= (1ull << 32)) return fail(c, KMC_ERR_ARG, "batch too large for one walk pass");
     const u32 nb = (u32)((n_reads + KMC_SCAN_PER_BLOCK - 1) / KMC_SCAN_PER_BLOCK);
     int rc = ensure(c, c->vr_cnt, (size_t)n_reads * sizeof(u32));
@@ -782,7 +780,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     if (!n_reads || !n_bases) return KMC_OK;
 
     int algo = c->cfg.algo;
-    if (c->cfg.mode == KMC_MODE_LR) algo = KMC_ALGO_STREAM;  // LR runs its own kernel (kmc_lr.cuh)
+    if (c->cfg.mode == KMC_MODE_LR) algo = KMC_ALGO_STREAM;  // LR runs its own kernel (kmc_lr.hip.h)
     if (algo == KMC_ALGO_AUTO && c->prefer_sort) algo = KMC_ALGO_SORT;
     if (algo == KMC_ALGO_AUTO || algo == KMC_ALGO_WALK) {
         if (!max_read_len) {
@@ -835,12 +833,17 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             return std::min<u64>(take, units_left);
         };
         double observed_kmers = 0.0;
+        u64 sk_seen = c->sk.lo ? c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] : 0;
         auto observe = [&](u64 occ_before, u64 units, u64 kmers_per_unit) -> int {
             int r = poll_and_settle(c);
             if (r) return r;
             if (c->recovered) return KMC_OK;
             u64 occ_after = c->h_counters[KMC_CTR_OCCUPIED];
-            double rho = (double)(occ_after > occ_before ? occ_after - occ_before : 0) / ((double)units * (double)kmers_per_unit);
+            // keys still waiting in the (k+16)-mer table count as well: each entry becomes up to 16 k-mers at the unfold
+            const u64 sk_after = c->sk.lo ? c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] : 0;
+            const u64 sk_new = sk_after > sk_seen ? sk_after - sk_seen : 0;
+            sk_seen = sk_after;
+            double rho = ((double)(occ_after > occ_before ? occ_after - occ_before : 0) + 16.0 * (double)sk_new) / ((double)units * (double)kmers_per_unit);
             c->rho_last = rho;
             c->rho_max = std::max(c->rho_max, rho);
             batch_rho_max = std::max(batch_rho_max, rho);
@@ -851,6 +854,24 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             observed_kmers += (double)units * (double)kmers_per_unit;
             u64 occ_all = occ_after + c->h_counters[KMC_CTR_SPILL];
             c->rho_hist = (double)(occ_all > c->b_occ0 ? occ_all - c->b_occ0 : 0) / std::max(observed_kmers, 1.0);
+            return KMC_OK;
+        };
+        // Give the counts of the (k+16)-mer table to their k-mers (kmc_sk_unfold_kernel).  What the last poll
+        // saw of that table is certain to come (16 k-mers per entry): room is made for it first.  Entries
+        // added since then are covered like any prediction: by the table saved in front of the launch
+        // that added them.  (Growing re-inserts the table, which a saved COPY of the table would not
+        // survive; a saved entry list does.)
+        auto flush_sk = [&]() -> int {
+            const u64 sk_known = c->h_sk_counters ? c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] : 0;
+            const u64 occ0 = c->h_counters[KMC_CTR_OCCUPIED];
+            if (sk_known && (occ0 + 16 * sk_known) * 10 > c->tab.cap * 7 && !(c->risky.armed && c->risky.mode == 2)) {
+                int r = grow_to(c, next_pow2((occ0 + 16 * sk_known) * 2));
+                if (r) return r;
+            }
+            int r = kmc_sk_unfold_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, sk_table_of(c), gtable_of(c, c->tab));
+            if (r) return fail(c, r, "(k+16)-mer unfold launch failed");
+            c->sk_dirty = false;
+            c->pending = true;
             return KMC_OK;
         };
         const bool lr = c->cfg.mode == KMC_MODE_LR;
@@ -871,7 +892,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 }
                 rc = launch_begin(c);
                 if (rc) return rc;
-                hipLaunchKernelGGL(kmc_lr_extract_kernel, dim3((unsigned)((p1 - p0 + KMC_LRX_POS - 1) / KMC_LRX_POS)), dim3(1024), 0, c->stream,
+                hipLaunchKernelGGL(kmc_lr_extract_kernel, dim3((unsigned)((p1 - p0 + KMC_LRX_POS - 1) / KMC_LRX_POS)), dim3(KMC_LRX_THREADS), 0, c->stream,
                                    d_bases, n_bases, d_offsets, n_reads, p0, p1, (u64*)c->s_hi[0].p, (u64*)c->s_lo[0].p, c->d_counters);
                 HIPCHK(c, hipGetLastError());
                 u64* const khi[2] = {(u64*)c->s_hi[0].p, (u64*)c->s_hi[1].p};
@@ -922,6 +943,18 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             while (done < n_tiles) {
                 u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
                 u64 take = plan(n_tiles - done, kpt, prev);
+                if (c->sk_dirty && take > plan_safe) {
+                    // A launch that rests on a prediction is about to save the table: the (k+16)-mer counts of
+                    // the launches before it must be IN that table first (a recovery drops the (k+16)-mer
+                    // table's counts together with the failed launch's).  This is a poll point: the unfold is
+                    // sized exactly, and one more poll tells the planner what the table looks like now.
+                    rc = flush_sk();
+                    if (rc) return rc;
+                    rc = poll_and_settle(c);
+                    if (rc) return rc;
+                    if (c->recovered) break;
+                    take = plan(n_tiles - done, kpt, prev);
+                }
                 if (take > plan_safe && !arm_risky(c, d_bases, d_offsets, n_reads, n_bases, 0, done ? d_ve + (done * 64 - 1) : nullptr))
                     take = plan_safe;  // (the table cannot be saved cheaply: stay within what fits for certain)
                 // the (k+16)-mer table takes one entry per step at most: a launch that could fill it is risky too;
@@ -929,6 +962,13 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 GTable skt = sk_table_of(c);
                 if (skt.key_lo && !c->risky.armed) {
                     const u64 max_adds = take * 64ull * (KMC_WALK_MAX_READ / KMC_WALK_STRIDE + 1);
+                    if ((c->h_sk_counters[KMC_CTR_OCCUPIED] + max_adds) * 4 > c->sk.cap * 3 && c->sk_dirty) {
+                        rc = flush_sk();   // (as above: nothing of earlier launches may be lost with this one)
+                        if (rc) return rc;
+                        rc = poll_and_settle(c);
+                        if (rc) return rc;
+                        if (c->recovered) break;
+                    }
                     if ((c->h_sk_counters[KMC_CTR_OCCUPIED] + max_adds) * 4 > c->sk.cap * 3 &&
                         !arm_risky(c, d_bases, d_offsets, n_reads, n_bases, 0, done ? d_ve + (done * 64 - 1) : nullptr))
                         skt = GTable{};
@@ -945,6 +985,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
                 rc = launch_end(c);
                 if (rc) return rc;
+                if (skt.key_lo) c->sk_dirty = true;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
                                      done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), skt, 1);
                 if (rc) return fail(c, rc, "scalar/unfold kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
@@ -957,7 +998,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                     rc = observe(occ, take, kpt);
                     if (rc) return rc;
                     if (c->recovered) break;  // (the sort path has counted the rest of the batch)
-                    if (c->cfg.algo == KMC_ALGO_AUTO && (c->walk_overflowed || (c->rho_last > 0.2 && (take >= 2048 || done * 2 >= n_tiles)))) {
+                    if (c->cfg.algo == KMC_ALGO_AUTO && (c->walk_overflowed || (c->rho_last > 0.5 && (take >= 2048 || done * 2 >= n_tiles)))) {
                         // (the new-key rate only counts once a launch was large or half the batch is through: the
                         // first tiles of ANY input are all new)
                         // the memos do not help on this input (both levels overflow, or more than one k-mer in
@@ -976,7 +1017,11 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 }
             }
         }
-        if (c->recovered) { run_stream = false; run_sort = false; }
+        if (c->sk_dirty && !c->recovered) {   // the batch's walk launches are through
+            rc = flush_sk();
+            if (rc) return rc;
+        }
+        if (c->recovered) { run_stream = false; run_sort = false; c->sk_dirty = false; }
         if (run_stream) {
             const u64 n_chunks = (n_bases + KMC_CHUNK - 1) / KMC_CHUNK;
             u64 done = stream_from / KMC_CHUNK, prev = 0;
@@ -1076,7 +1121,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
                       &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1],
                       &c->m_hist, &c->m_stot, &c->m_bsum, &c->m_rmin, &c->m_rmax, &c->m_seg[0], &c->m_seg[1], &c->m_first, &c->m_cbase, &c->m_skip, &c->m_term, &c->m_ord,
                       &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_cnt, &c->m_w[0], &c->m_w[1],
-                      &c->snap_hi, &c->snap_lo, &c->snap_cnt, &c->snap_n, &c->snap_occ};
+                      &c->snap_hi, &c->snap_lo, &c->snap_cnt, &c->snap_n, &c->snap_occ, &c->rx_hi, &c->rx_lo, &c->rx_cnt};
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     free_table(c->sk);
     if (c->d_sk_counters) (void)hipFree(c->d_sk_counters);
@@ -1278,7 +1323,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         n_kmers = r.total;
     } else if (n) {
         // table entries and / or several runs: ONE weighted sort merges and orders them -- the entries are
-        // concatenated as (key, count) pairs, the hand-written radix sort (kmc_msd.cuh) orders them and
+        // concatenated as (key, count) pairs, the hand-written radix sort (kmc_msd.hip.h) orders them and
         // its run-length step sums the counts of equal keys (the grouping of main.rs:84,87 once more)
         if (n >= (1ull << 32) - KMC_MSD_RANGE) return fail(c, KMC_ERR_ARG, "kmc_finalize: more than 2^32 table entries + run entries to merge in one pass");
         if (!c->runs.empty()) {
@@ -1597,31 +1642,136 @@ static int count_file_pipeline(kmc_ctx** ctxs, uint32_t n_ctx, const char* path,
         }
         return KMC_OK;
     };
-    rc = body();
-    cleanup();
-    if (rc) return rc;
-    // reduce: every other GPU's sorted table is copied to ctxs[0]'s GPU (peer copy: xGMI) and merged there
-    for (uint32_t i = 1; i < n_ctx; ++i) {
-        kmc_ctx* c = ctxs[i];
-        u64 nd = 0, nt = 0;
-        rc = kmc_finalize(c, &nd, &nt);
-        if (rc) { memcpy(c0->err, c->err, sizeof(c0->err)); return rc; }
-        if (!nd) continue;
-        HIPCHK(c0, hipSetDevice(c0->cfg.device));
-        const int words = c0->KW + 1;
-        u64* tmp = nullptr;
-        HIPCHK(c0, hipMalloc((void**)&tmp, (size_t)nd * words * sizeof(u64)));
-        hipError_t e = hipMemcpyPeerAsync(tmp, c0->cfg.device, c->v_lo, c->cfg.device, (size_t)nd * sizeof(u64), c0->stream);
-        if (e == hipSuccess) e = hipMemcpyPeerAsync(tmp + nd, c0->cfg.device, c->v_cnt, c->cfg.device, (size_t)nd * sizeof(u64), c0->stream);
-        if (e == hipSuccess && c0->KW == 2) e = hipMemcpyPeerAsync(tmp + 2 * nd, c0->cfg.device, c->v_hi, c->cfg.device, (size_t)nd * sizeof(u64), c0->stream);
-        if (e == hipSuccess) {
-            rc = kmc_merge_pairs_device(c0, c0->KW == 2 ? tmp + 2 * nd : nullptr, tmp, tmp + nd, nd);
-            if (!rc) e = hipStreamSynchronize(c0->stream);
-        }
-        (void)hipFree(tmp);
-        if (e != hipSuccess) return fail(c0, KMC_ERR_HIP, "peer copy from device %d failed: %s", c->cfg.device, hipGetErrorString(e));
+    // One GPU: parse chunk j+1 while the GPU uploads and counts chunk j (body()).  Several GPUs: ONE FEEDER
+    // THREAD PER GPU, each with its own pinned pair, parsing the chunks i, i+N, i+2N, ... of the mapped file
+    // itself (the first version parsed every chunk in one host loop and dealt them out round-robin: N GPUs
+    // waited on one parser).  The parser threads of the host are split between the feeders.
+    if (n_ctx == 1) {
+        rc = body();
+        cleanup();
         if (rc) return rc;
+    } else {
+        cleanup();  // (nothing allocated yet; the feeders own their buffers)
+        const size_t n_chunks = ing.n_chunks();
+        const unsigned per = std::max(1u, ing.threads() / n_ctx);
+        std::atomic<long long> stop_at{LLONG_MAX};   // first chunk in which an empty record ended the input
+        std::vector<int> frc(n_ctx, KMC_OK);
+        std::vector<long long> queued_max(n_ctx, -1);
+        auto feed = [&](uint32_t i) {
+            kmc_ctx* c = ctxs[i];
+            Pinned pp[2];
+            auto fin = [&]() {
+                (void)hipStreamSynchronize(c->stream);
+                for (auto& p : pp) { if (p.bases) (void)hipHostFree(p.bases); if (p.offs) (void)hipHostFree(p.offs); if (p.ev) (void)hipEventDestroy(p.ev); }
+            };
+            auto run = [&]() -> int {
+                HIPCHK(c, hipSetDevice(c->cfg.device));
+                KmcIngestChunk ck;
+                std::string e2;
+                size_t it = 0;
+                for (size_t j = i; j < n_chunks; j += n_ctx, ++it) {
+                    if ((long long)j > stop_at.load()) break;
+                    Pinned& p = pp[it & 1];
+                    if (!p.bases) {
+                        HIPCHK(c, hipHostMalloc((void**)&p.bases, (size_t)cap));
+                        HIPCHK(c, hipEventCreateWithFlags(&p.ev, hipEventDisableTiming));
+                    }
+                    if (p.busy) { HIPCHK(c, hipEventSynchronize(p.ev)); p.busy = false; }
+                    int r;
+                    try { r = ing.parse_chunk(j, per, p.bases, false, &ck, &e2); } catch (const std::bad_alloc&) { return fail(c, KMC_ERR_NOMEM, "out of memory while parsing %s", path); }
+                    if (r) return fail(c, r, "%s: %s", path, e2.c_str());
+                    if (ck.terminated) { long long cur = stop_at.load(); while ((long long)j < cur && !stop_at.compare_exchange_weak(cur, (long long)j)) {} }
+                    if ((long long)j > stop_at.load()) break;
+                    if (!ck.n_reads) continue;
+                    if (p.offs_cap < ck.n_reads + 1) {
+                        if (p.offs) { HIPCHK(c, hipHostFree(p.offs)); p.offs = nullptr; }
+                        p.offs_cap = (ck.n_reads + 1) * 5 / 4 + 1024;
+                        HIPCHK(c, hipHostMalloc((void**)&p.offs, (size_t)p.offs_cap * sizeof(u64)));
+                    }
+                    memcpy(p.offs, ck.offsets.data(), (size_t)(ck.n_reads + 1) * sizeof(u64));
+                    if (c->pending) { r = poll_and_settle(c); if (r) return r; }
+                    r = ensure(c, c->st_bases, ck.n_bases + 64);
+                    if (r) return r;
+                    r = ensure(c, c->st_offsets, (ck.n_reads + 1) * sizeof(u64));
+                    if (r) return r;
+                    for (const auto& pc : ck.pieces)
+                        HIPCHK(c, hipMemcpyAsync((uint8_t*)c->st_bases.p + pc.dst_off, p.bases + pc.src_off, (size_t)pc.n_bytes, hipMemcpyHostToDevice, c->stream));
+                    HIPCHK(c, hipMemcpyAsync(c->st_offsets.p, p.offs, (size_t)(ck.n_reads + 1) * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+                    HIPCHK(c, hipEventRecord(p.ev, c->stream));
+                    p.busy = true;
+                    r = count_batch_device(c, (const uint8_t*)c->st_bases.p, (const u64*)c->st_offsets.p, ck.n_reads, ck.n_bases, ck.max_read_len);
+                    if (r) return r;
+                    queued_max[i] = (long long)j;
+                }
+                return KMC_OK;
+            };
+            int r;
+            try { r = run(); } catch (const std::bad_alloc&) { r = fail(c, KMC_ERR_NOMEM, "out of host memory"); } catch (...) { r = fail(c, KMC_ERR_HIP, "internal error in a feeder thread"); }
+            frc[i] = r;
+            fin();
+        };
+        {
+            std::vector<std::thread> th;
+            th.reserve(n_ctx);
+            struct Join { std::vector<std::thread>& t; ~Join() { for (auto& x : t) if (x.joinable()) x.join(); } } join{th};
+            for (uint32_t i = 1; i < n_ctx; ++i) th.emplace_back(feed, i);
+            feed(0);
+        }
+        for (uint32_t i = 0; i < n_ctx; ++i)
+            if (frc[i]) { if (i) memcpy(c0->err, ctxs[i]->err, sizeof(c0->err)); return frc[i]; }
+        bool raced = false;  // a chunk behind the terminating record was counted before that record was found
+        for (uint32_t i = 0; i < n_ctx; ++i) raced |= queued_max[i] > stop_at.load();
+        if (raced) {
+            for (uint32_t i = 0; i < n_ctx; ++i) { int r = kmc_reset(ctxs[i]); if (r) return r; }
+            KmcFastaIngest again;
+            std::string e3;
+            rc = again.open(path, chunk_bytes, &e3);
+            if (rc) return fail(c0, rc, "%s: %s", path, e3.c_str());
+            // (the sequential loop stops exactly at the terminating record)
+            KmcIngestChunk ck;
+            std::vector<uint8_t> hostbuf((size_t)again.chunk_capacity());
+            for (u64 j = 0;; ++j) {
+                kmc_ctx* c = ctxs[j % n_ctx];
+                int r = again.next(hostbuf.data(), false, &ck, &e3);
+                if (r) return fail(c0, r, "%s: %s", path, e3.c_str());
+                if (ck.n_reads) {
+                    std::vector<uint8_t> dense((size_t)ck.n_bases);
+                    for (const auto& pc : ck.pieces) memcpy(dense.data() + pc.dst_off, hostbuf.data() + pc.src_off, (size_t)pc.n_bytes);
+                    r = kmc_add_batch(c, dense.data(), ck.offsets.data(), ck.n_reads);
+                    if (r) { if (c != c0) memcpy(c0->err, c->err, sizeof(c0->err)); return r; }
+                }
+                if (ck.eof) break;
+            }
+        }
     }
+    // reduce: pairwise (a tree of depth log2 N): in round r the contexts i with i % 2^(r+1) == 0 take the sorted
+    // table of context i + 2^r over a peer copy (xGMI) into receive buffers they keep, and merge it; the pairs
+    // of a round run side by side.  ctxs[0] ends up with everything.  (The first version finalized, allocated
+    // and copied every other GPU's table into GPU 0 one after the other.)
+    for (uint32_t stride = 1; stride < n_ctx; stride *= 2) {
+        for (uint32_t i = 0; i + stride < n_ctx; i += 2 * stride) {
+            kmc_ctx *dst = ctxs[i], *src = ctxs[i + stride];
+            u64 nd = 0, nt = 0;
+            rc = kmc_finalize(src, &nd, &nt);
+            if (rc) { memcpy(c0->err, src->err, sizeof(c0->err)); return rc; }
+            if (!nd) continue;
+            HIPCHK(c0, hipSetDevice(dst->cfg.device));
+            const size_t nb = (size_t)nd * sizeof(u64);
+            rc = ensure(dst, dst->rx_lo, nb); if (!rc) rc = ensure(dst, dst->rx_cnt, nb); if (!rc && dst->KW == 2) rc = ensure(dst, dst->rx_hi, nb);
+            if (rc) { if (dst != c0) memcpy(c0->err, dst->err, sizeof(c0->err)); return rc; }
+            hipError_t e = hipMemcpyPeerAsync(dst->rx_lo.p, dst->cfg.device, src->v_lo, src->cfg.device, nb, dst->stream);
+            if (e == hipSuccess) e = hipMemcpyPeerAsync(dst->rx_cnt.p, dst->cfg.device, src->v_cnt, src->cfg.device, nb, dst->stream);
+            if (e == hipSuccess && dst->KW == 2) e = hipMemcpyPeerAsync(dst->rx_hi.p, dst->cfg.device, src->v_hi, src->cfg.device, nb, dst->stream);
+            if (e != hipSuccess) return fail(c0, KMC_ERR_HIP, "peer copy from device %d failed: %s", src->cfg.device, hipGetErrorString(e));
+            rc = kmc_merge_pairs_device(dst, dst->KW == 2 ? dst->rx_hi.p : nullptr, dst->rx_lo.p, dst->rx_cnt.p, nd);
+            if (rc) { if (dst != c0) memcpy(c0->err, dst->err, sizeof(c0->err)); return rc; }
+        }
+        for (uint32_t i = 0; i + stride < n_ctx; i += 2 * stride) {  // the round's copies and merges have finished
+            HIPCHK(c0, hipSetDevice(ctxs[i]->cfg.device));
+            HIPCHK(c0, hipStreamSynchronize(ctxs[i]->stream));
+        }
+    }
+    HIPCHK(c0, hipSetDevice(c0->cfg.device));
     return kmc_finalize(c0, n_distinct, n_total);
 }
 

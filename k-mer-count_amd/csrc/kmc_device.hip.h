@@ -1,4 +1,4 @@
-// kmc_device.cuh -- device-side building blocks shared by the gfx950 kernels.
+// kmc_device.hip.h -- device-side building blocks shared by the gfx950 kernels.
 //
 // Written for CDNA4 (wave64, LDS atomics, v_alignbit/v_perm/v_bfrev) only; there is no other
 // backend.  Semantics follow SURVEY.md 8a-def: alphabet A=0 C=1 G=2 T=3 (reference

@@ -20,7 +20,7 @@
 #include <vector>
 
 #include "../../include/kmc.h"
-#include "kmc_synth.cuh"
+#include "kmc_synth.hip.h"
 
 namespace {
 
@@ -371,18 +371,23 @@ int KmcFastaIngest::open(const char* path, uint64_t chunk_bytes, std::string* er
 
 uint64_t KmcFastaIngest::chunk_capacity() const { return cap_; }
 
-int KmcFastaIngest::next(uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* ck, std::string* err) {
+size_t KmcFastaIngest::n_chunks() const { return cuts_.size() > 1 ? cuts_.size() - 1 : 0; }
+
+// Chunk `idx` on its own (no reader state is touched: several feeder threads may parse different chunks of
+// one file at the same time).  ck->terminated tells that a record with an empty header and no sequence
+// ended the input inside this chunk (Record::is_empty(), main.rs:60-62): nothing after it counts.
+int KmcFastaIngest::parse_chunk(size_t idx, unsigned threads, uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* ck, std::string* err) const {
     ck->pieces.clear();
     ck->offsets.assign(1, 0);
     ck->n_reads = ck->n_bases = ck->max_read_len = 0;
     ck->bad_byte = -1;
     ck->eof = true;
-    if (done_ || next_cut_ + 1 >= cuts_.size()) { done_ = true; return KMC_OK; }
-    const uint64_t cb = cuts_[next_cut_], ce = cuts_[next_cut_ + 1];
-    next_cut_++;
+    ck->terminated = false;
+    if (idx + 1 >= cuts_.size()) return KMC_OK;
+    const uint64_t cb = cuts_[idx], ce = cuts_[idx + 1];
     // segments of >= 4 MiB, snapped forward to line starts
     const uint64_t len = ce - cb;
-    uint64_t nseg = std::min<uint64_t>(threads_, std::max<uint64_t>(1, len >> 22));
+    uint64_t nseg = std::min<uint64_t>(std::max(1u, threads), std::max<uint64_t>(1, len >> 22));
     std::vector<uint64_t> sb((size_t)nseg + 1);
     sb[0] = cb;
     for (uint64_t i = 1; i < nseg; ++i) {
@@ -410,9 +415,9 @@ int KmcFastaIngest::next(uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* 
     for (auto& p : po) if (p.oom) throw std::bad_alloc();  // (callers turn it into KMC_ERR_NOMEM)
     if (fastq_) {
         for (auto& p : po)
-            if (p.bad_first_line) { if (err) *err = "malformed FASTQ record (expected '@' header and '+' separator lines)"; done_ = true; return KMC_ERR_FORMAT; }
+            if (p.bad_first_line) { if (err) *err = "malformed FASTQ record (expected '@' header and '+' separator lines)"; return KMC_ERR_FORMAT; }
     }
-    if (po[0].bad_first_line) { if (err) *err = "Expected > at record start."; done_ = true; return KMC_ERR_FORMAT; }
+    if (po[0].bad_first_line) { if (err) *err = "Expected > at record start."; return KMC_ERR_FORMAT; }
     uint64_t base = 0;
     std::vector<uint8_t> blank;
     ck->offsets.clear();
@@ -424,7 +429,7 @@ int KmcFastaIngest::next(uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* 
     }
     uint64_t nrec = ck->offsets.size();
     ck->offsets.push_back(base);
-    ck->eof = next_cut_ + 1 >= cuts_.size();
+    ck->eof = idx + 2 >= cuts_.size();
     // Record::is_empty(): a record with empty header and no sequence ends the input (main.rs:60-62)
     for (uint64_t i = 0; i < nrec && !fastq_; ++i) {
         if (blank[(size_t)i] && ck->offsets[(size_t)i + 1] == ck->offsets[(size_t)i]) {
@@ -440,17 +445,33 @@ int KmcFastaIngest::next(uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* 
             }
             ck->pieces.swap(keep);
             ck->eof = true;
-            done_ = true;
+            ck->terminated = true;
             break;
         }
     }
-    if (ck->eof) done_ = true;
     ck->n_reads = nrec;
     ck->n_bases = base;
     uint64_t m = 0;
     for (uint64_t i = 0; i < nrec; ++i) m = std::max<uint64_t>(m, ck->offsets[(size_t)i + 1] - ck->offsets[(size_t)i]);
     ck->max_read_len = m;
     return KMC_OK;
+}
+
+int KmcFastaIngest::next(uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* ck, std::string* err) {
+    if (done_ || next_cut_ + 1 >= cuts_.size()) {
+        ck->pieces.clear();
+        ck->offsets.assign(1, 0);
+        ck->n_reads = ck->n_bases = ck->max_read_len = 0;
+        ck->bad_byte = -1;
+        ck->eof = true;
+        ck->terminated = false;
+        done_ = true;
+        return KMC_OK;
+    }
+    const int rc = parse_chunk(next_cut_, threads_, out_buf, check_alphabet, ck, err);
+    next_cut_++;
+    if (rc || ck->eof) done_ = true;
+    return rc;
 }
 
 // ---- public streaming form: dense host buffers, one chunk at a time -----------------------------

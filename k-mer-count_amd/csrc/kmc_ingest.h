@@ -29,6 +29,7 @@ struct KmcIngestChunk {
     std::vector<uint64_t> offsets;  // n_reads + 1, dense coordinates
     uint64_t n_reads = 0, n_bases = 0, max_read_len = 0;
     bool eof = false;               // nothing follows this chunk
+    bool terminated = false;        // an empty record ended the input inside this chunk (nothing after it counts)
     int bad_byte = -1;              // first byte outside ACGT (only looked for when asked)
 };
 
@@ -42,6 +43,11 @@ class KmcFastaIngest {
     // Parse the next chunk into `out_buf` (chunk_capacity() bytes).  KMC_OK (chunk->eof tells whether more
     // follows; a chunk may hold zero reads), KMC_ERR_FORMAT ("Expected > at record start.").
     int next(uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* chunk, std::string* err);
+    // The same for chunk `idx` (0 .. n_chunks()-1) without touching the reader's position: feeder threads of a
+    // multi-GPU run parse different chunks of one file concurrently, `threads` parser threads each.
+    size_t n_chunks() const;
+    unsigned threads() const { return threads_; }
+    int parse_chunk(size_t idx, unsigned threads, uint8_t* out_buf, bool check_alphabet, KmcIngestChunk* chunk, std::string* err) const;
 
   private:
     const char* map_ = nullptr;

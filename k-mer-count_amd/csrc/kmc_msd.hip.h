@@ -1,4 +1,4 @@
-// kmc_msd.cuh -- hand-written MSD radix sort + run-length for packed k-mer keys: the GPU form of the
+// kmc_msd.hip.h -- hand-written MSD radix sort + run-length for packed k-mer keys: the GPU form of the
 // reference's grouping step, bucket_sort / radix_sort / sort() + "count the repeated lines"
 // (k-mer-count/src/main.rs:9-40,84,87), for inputs where almost every key is new (KMC_ALGO_SORT, the
 // reference's own LR mode) and for ordering large count tables.
@@ -27,7 +27,7 @@
 // and are dropped.  Keys may carry a 64-bit weight (an existing count): the run-length then sums
 // weights -- that is how count tables and earlier runs are merged and ordered.
 #pragma once
-#include "kmc_device.cuh"
+#include "kmc_device.hip.h"
 
 #define KMC_MSD_RANGE 65536   // keys per histogram / scatter workgroup (a histogram row of 1025 counters per range)
 #define KMC_MSD_BITS 10       // digit width of a level (the last level of a key may be narrower)
@@ -35,13 +35,24 @@
 #define KMC_MSD_NB (KMC_MSD_ND + 1)   // digit bins + "invalid position"
 #define KMC_MSD_THREADS 256
 #define KMC_MSD_LEAF1 2048    // leaf capacity, one-word keys  (two LDS images of 16 KB: four leaves per CU in flight)
-#define KMC_MSD_LEAF2 1024    // leaf capacity, two-word keys
+#ifndef KMC_MSD_LEAF2
+#define KMC_MSD_LEAF2 1024    // leaf capacity, two-word keys without weights (2048: random 63-mers 88 -> 66 ms, but clustered keys 90 -> 112 ms and the LR mode 8.1 -> 9.2 ms)
+#endif
+#define KMC_MSD_LEAF2W 1024   // leaf capacity, two-word keys with weights
 #define KMC_MSD_THREAD_SORT 32  // sub-buckets up to this size are insertion-sorted by one thread
 #define KMC_MSD_LEAF_LOGNSB 9
 #define KMC_MSD_LEAF_NSB (1 << KMC_MSD_LEAF_LOGNSB)   // sub-buckets of a leaf: three or four keys each, so the per-thread insertion sorts
                                 // (a chain of dependent LDS round trips per move) stay a handful of moves long
 
-struct MsdSeg { u32 begin, len; };
+// hib = key bits still unsorted in the segment: its keys agree above bit hib, the next digit is bits
+// [hib - w, hib) with w = min(hib, 10).  (Per segment, not per level: a segment whose keys turn out to
+// share a long prefix -- the junction k-mers of repetitive input, the 61 LR keys of one window start --
+// jumps over that prefix instead of taking one level per ten bits of it: when a level finds all keys
+// of a segment in ONE digit, the segment is not moved; it is queued again, where it lies, with hib at the
+// highest bit in which its smallest and largest key differ.)
+struct MsdSeg { u32 begin, len, hib, parity; };  // parity: which of the two key buffers holds the segment
+__device__ __forceinline__ int msd_seg_shift(u32 hib) { return hib > KMC_MSD_BITS ? (int)hib - KMC_MSD_BITS : 0; }
+__device__ __forceinline__ u32 msd_seg_mask(u32 hib) { return hib >= KMC_MSD_BITS ? (u32)KMC_MSD_ND - 1u : (1u << hib) - 1u; }
 // kind 0: leaf (sort in LDS); kind 1: all keys equal (one pair, key = first element)
 struct MsdTerm { u32 begin, len, kind, parity; };
 
@@ -169,8 +180,9 @@ __device__ __forceinline__ u32 msd_seg_of(const u32* __restrict__ first, u32 n_s
 // per range: digit histogram (hist[r][NB]) and min / max key (all-equal segments end here)
 template <int KW>
 __global__ __launch_bounds__(KMC_MSD_THREADS)
-void kmc_msd_hist_kernel(const u64* __restrict__ khi, const u64* __restrict__ klo, const MsdSeg* __restrict__ seg, u32 n_seg,
-                         const u32* __restrict__ first, int shift, u32 mask, int kb, int level0,
+void kmc_msd_hist_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo0, const u64* __restrict__ hi1, const u64* __restrict__ lo1,
+                         const MsdSeg* __restrict__ seg, u32 n_seg,
+                         const u32* __restrict__ first, int kb, int level0,
                          u32* __restrict__ hist, u64* __restrict__ rmin, u64* __restrict__ rmax, const MsdCtl* __restrict__ ctl) {
     __shared__ u32 h[4][KMC_MSD_NB + 3];
     __shared__ u64 smin[4][2], smax[4][2];
@@ -182,6 +194,10 @@ void kmc_msd_hist_kernel(const u64* __restrict__ khi, const u64* __restrict__ kl
     const u32 idx = r - first[s];
     const u32 b = seg[s].begin + idx * KMC_MSD_RANGE;
     const u32 n = min((u32)KMC_MSD_RANGE, seg[s].len - idx * KMC_MSD_RANGE);
+    const int shift = msd_seg_shift(seg[s].hib);
+    const u32 mask = msd_seg_mask(seg[s].hib);
+    const u64* const khi = seg[s].parity ? hi1 : hi0;
+    const u64* const klo = seg[s].parity ? lo1 : lo0;
     u64 mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
     for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
         const u64 lo = klo[b + i], hi = KW == 2 ? khi[b + i] : 0ull;
@@ -224,6 +240,7 @@ void kmc_msd_scan_a_kernel(u32 n_seg, u32 S, const u32* __restrict__ first, u32*
     const u32 s = blockIdx.x / S, j = blockIdx.x % S, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (s >= n_seg) return;
     const u32 r0 = first[s], r1 = first[s + 1];
+    if (r1 - r0 == 1) return;  // one range: its histogram IS the total (kmc_msd_scan_kernel takes it from there)
     for (u32 d = j * 4 + wv; d < KMC_MSD_NB; d += 4 * S) {
         u32 run = 0;
         for (u32 base = r0; base < r1; base += 64) {
@@ -245,9 +262,9 @@ void kmc_msd_scan_a_kernel(u32 n_seg, u32 S, const u32* __restrict__ first, u32*
 //   seg_skip[s] = 1: every key of the segment is equal -- it becomes a terminal as it stands (in the
 //   SOURCE buffer) and its ranges are not scattered.
 __global__ __launch_bounds__(KMC_MSD_ND)
-void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* __restrict__ first, const u32* __restrict__ stot,
+void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* __restrict__ first, u32* __restrict__ hist, const u32* __restrict__ stot,
                          const u64* __restrict__ rmin, const u64* __restrict__ rmax, u32* __restrict__ cbase, u32* __restrict__ seg_skip,
-                         int last_level, int level0, u32 leaf_cap, u32 src_parity,
+                         int level0, u32 leaf_cap,
                          MsdSeg* __restrict__ next, u32 next_cap, MsdTerm* __restrict__ term, u32 term_cap,
                          unsigned long long* __restrict__ bitmap, MsdCtl* ctl) {
     constexpr int NWV = KMC_MSD_ND / 64;
@@ -274,9 +291,14 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
         }
         if (lane == 0) { smm[wv][0] = mnh; smm[wv][1] = mnl; smm[wv][2] = mxh; smm[wv][3] = mxl; }
     }
-    for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_ND) tot[d] = stot[(size_t)s * KMC_MSD_NB + d];
+    if (r1 - r0 == 1) {  // a segment of one range (most segments below level 0): no column scan was run for it
+        for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_ND) { tot[d] = hist[(size_t)r0 * KMC_MSD_NB + d]; hist[(size_t)r0 * KMC_MSD_NB + d] = 0; }
+    } else {
+        for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_ND) tot[d] = stot[(size_t)s * KMC_MSD_NB + d];
+    }
     __syncthreads();
     bool all_equal;
+    int top_diff = -1;  // highest bit in which two keys of the segment differ
     {
         u64 mnh = smm[0][0], mnl = smm[0][1], mxh = smm[0][2], mxl = smm[0][3];
         for (int w = 1; w < NWV; ++w) {
@@ -284,7 +306,13 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
             if (key_less(mxh, mxl, smm[w][2], smm[w][3])) { mxh = smm[w][2]; mxl = smm[w][3]; }
         }
         all_equal = mnh == mxh && mnl == mxl;
+        const u64 xh = mnh ^ mxh, xl = mnl ^ mxl;
+        if (xh) top_diff = 127 - __clzll((long long)xh);
+        else if (xl) top_diff = 63 - __clzll((long long)xl);
     }
+    const int shift = msd_seg_shift(seg[s].hib);
+    const bool last_level = shift == 0;
+    const u32 src_parity = seg[s].parity;
     const u32 n_filler = level0 ? tot[KMC_MSD_ND] : 0;
     const bool equal = all_equal && seg[s].len > n_filler && (!level0 || n_filler == 0);
     // exclusive scan of tot[0..ND) -> child begin (the filler bucket is dropped)
@@ -300,58 +328,81 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
     cbase[(size_t)s * KMC_MSD_NB + tid] = cb;
     cb_s[tid] = cb;
     __syncthreads();
-    if (tid != 0) return;
-    cbase[(size_t)s * KMC_MSD_NB + KMC_MSD_ND] = 0;
-    seg_skip[s] = equal ? 1u : 0u;
-    if (level0) ctl->n_valid = seg[s].len - n_filler;
-    if (equal) {  // stays where it is (source buffer): one pair
-        const u32 i = atomicAdd(&ctl->n_term, 1u);
-        if (i < term_cap) {
-            term[i] = MsdTerm{seg[s].begin, seg[s].len, 1u, src_parity};
-            atomicOr(&bitmap[seg[s].begin >> 6], 1ull << (seg[s].begin & 63));
-        } else atomicOr(&ctl->overflow, 1u);
-        return;
+    // What the segment turns into.  Wave 0 decides, the other fifteen are done (a workgroup that waits for
+    // one thread holds a thousand thread slots: with 400 k segments per level that tripled the kernel).
+    // The 1024 totals sit in wave 0's registers, sixteen per lane; the walk over them is wave-uniform
+    // (v_readlane, everything in scalar registers) and skips empty digits by ballot; the lists go to LDS
+    // and all 64 lanes write them out.  (The first version had thread 0 read every total from LDS, store
+    // every list entry to global memory and set its bitmap bit itself, in two passes: 120-280 us per
+    // level even for a single segment -- a fifth of the LR mode's sort.)
+    //   - all keys equal: a terminal as it stands (source buffer), one pair
+    //   - every key in ONE digit (they agree above bit top_diff, which lies below this digit): the segment
+    //     stays where it is and is queued again at the first bit that splits it
+    //   - otherwise its children, in position order: large ones go on to the next level (or, with no bits
+    //     left, are one pair each); runs of consecutive small ones are merged into leaves of at most
+    //     leaf_cap keys (a leaf sorts whatever keys it holds, so it need not be a single child)
+    __shared__ u32 l_tb[KMC_MSD_ND], l_tl[KMC_MSD_ND], l_tk[KMC_MSD_ND], l_nb[KMC_MSD_ND], l_nl[KMC_MSD_ND];
+    if (wv != 0) return;
+    const bool nomove = !equal && !last_level && top_diff >= 0 && top_diff < shift && n_filler == 0;
+    if (lane == 0) {
+        cbase[(size_t)s * KMC_MSD_NB + KMC_MSD_ND] = 0;
+        seg_skip[s] = (equal || nomove) ? 1u : 0u;
+        if (level0) ctl->n_valid = seg[s].len - n_filler;
     }
-    // children, in position order: large ones go on to the next level (or, with no bits left, are one
-    // pair each); runs of consecutive small ones are merged into leaves of at most leaf_cap keys (a
-    // leaf sorts whatever keys it holds, so it need not be a single child).  Two passes over the 1024
-    // totals: count what will be emitted, reserve the list space with ONE returning atomic per list
-    // (a returning atomic per terminal cost 1.6 ms per level), then write.
-    u32 t_base = 0, n_base = 0;
-    for (int pass = 0; pass < 2; ++pass) {
-        u32 nt = 0, nn = 0;
-        auto emit_term = [&](u32 b, u32 l, u32 kind, u32 parity) {
-            if (pass) {
-                const u32 i = t_base + nt;
-                if (i < term_cap) {
-                    term[i] = MsdTerm{b, l, kind, parity};
-                    atomicOr(&bitmap[b >> 6], 1ull << (b & 63));
-                }
-            }
-            ++nt;
-        };
+    u32 nt = 0, nn = 0;
+    u32 q_hib = (u32)shift, q_par = src_parity ^ 1u, t_par = src_parity ^ 1u;
+    if (equal) {
+        if (lane == 0) { l_tb[0] = seg[s].begin; l_tl[0] = seg[s].len; l_tk[0] = 1u; }
+        nt = 1; t_par = src_parity;
+    } else if (nomove) {
+        if (lane == 0) { l_nb[0] = seg[s].begin; l_nl[0] = seg[s].len; }
+        nn = 1; q_hib = (u32)(top_diff + 1); q_par = src_parity;
+    } else {
+        u32 T[NWV], C[NWV];
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) { T[j] = tot[j * 64 + lane]; C[j] = cb_s[j * 64 + lane]; }
         u32 gb = 0, gl = 0;
-        for (u32 d = 0; d < KMC_MSD_ND; ++d) {
-            const u32 m = tot[d];
-            if (!m) continue;
-            if (m > leaf_cap) {
-                if (gl) { emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u); gl = 0; }
-                if (last_level) emit_term(cb_s[d], m, 1u, src_parity ^ 1u);
-                else {
-                    if (pass && n_base + nn < next_cap) next[n_base + nn] = MsdSeg{cb_s[d], m};
-                    ++nn;
+        auto flush = [&]() { if (lane == 0) { l_tb[nt] = gb; l_tl[nt] = gl; l_tk[nt] = gl == 1 ? 1u : 0u; } ++nt; gl = 0; };
+#pragma unroll
+        for (int j = 0; j < NWV; ++j) {
+            unsigned long long live = __builtin_amdgcn_ballot_w64(T[j] != 0);
+            while (live) {
+                const int bl = (int)__builtin_ctzll(live);
+                live &= live - 1;
+                const u32 m = (u32)__builtin_amdgcn_readlane((int)T[j], bl);
+                const u32 cbv = (u32)__builtin_amdgcn_readlane((int)C[j], bl);
+                if (m > leaf_cap) {
+                    if (gl) flush();
+                    if (last_level) { if (lane == 0) { l_tb[nt] = cbv; l_tl[nt] = m; l_tk[nt] = 1u; } ++nt; }
+                    else { if (lane == 0) { l_nb[nn] = cbv; l_nl[nn] = m; } ++nn; }
+                } else {
+                    if (gl && gl + m > leaf_cap) flush();
+                    if (!gl) gb = cbv;
+                    gl += m;
                 }
-            } else {
-                if (gl && gl + m > leaf_cap) { emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u); gl = 0; }
-                if (!gl) gb = cb_s[d];
-                gl += m;
             }
         }
-        if (gl) emit_term(gb, gl, gl == 1 ? 1u : 0u, src_parity ^ 1u);
-        if (!pass) {
-            if (nt) { t_base = atomicAdd(&ctl->n_term, nt); if (t_base + nt > term_cap) atomicOr(&ctl->overflow, 1u); }
-            if (nn) { n_base = atomicAdd(&ctl->n_next, nn); if (n_base + nn > next_cap) atomicOr(&ctl->overflow, 2u); }
-        }
+        if (gl) flush();
+    }
+    u32 t_base = 0, n_base = 0;  // ONE returning atomic per list (one per terminal cost 1.6 ms per level)
+    if (lane == 0) {
+        if (nt) { t_base = atomicAdd(&ctl->n_term, nt); if (t_base + nt > term_cap) atomicOr(&ctl->overflow, 1u); }
+        if (nn) { n_base = atomicAdd(&ctl->n_next, nn); if (n_base + nn > next_cap) atomicOr(&ctl->overflow, 2u); }
+    }
+    t_base = (u32)__builtin_amdgcn_readfirstlane((int)t_base);
+    n_base = (u32)__builtin_amdgcn_readfirstlane((int)n_base);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    for (u32 i = lane; i < nt; i += 64) {
+        if (t_base + i >= term_cap) break;
+        const u32 bg = l_tb[i];
+        term[t_base + i] = MsdTerm{bg, l_tl[i], l_tk[i], t_par};
+        atomicOr(&bitmap[bg >> 6], 1ull << (bg & 63));
+    }
+    for (u32 i = lane; i < nn; i += 64) {
+        if (n_base + i >= next_cap) break;
+        next[n_base + i] = MsdSeg{l_nb[i], l_nl[i], q_hib, q_par};
     }
 }
 
@@ -373,11 +424,11 @@ template <int KW, bool WEIGHTS> struct MsdScatterLds {
 };
 template <int KW, bool WEIGHTS>
 __global__ __launch_bounds__(1024)
-void kmc_msd_scatter_kernel(const u64* __restrict__ khi, const u64* __restrict__ klo, const u64* __restrict__ kw,
-                            u64* __restrict__ ohi, u64* __restrict__ olo, u64* __restrict__ ow,
+void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* __restrict__ w0,
+                            u64* __restrict__ hi1, u64* __restrict__ lo1, u64* __restrict__ w1,
                             const MsdSeg* __restrict__ seg, u32 n_seg, const u32* __restrict__ first,
                             const u32* __restrict__ hist, const u32* __restrict__ cbase, const u32* __restrict__ seg_skip,
-                            int shift, u32 mask, int kb, int level0, const MsdCtl* __restrict__ ctl) {
+                            int kb, int level0, const MsdCtl* __restrict__ ctl) {
     extern __shared__ __align__(16) unsigned char msd_smem[];
     typedef MsdScatterLds<KW, WEIGHTS> LT;
     LT& L = *reinterpret_cast<LT*>(msd_smem);
@@ -386,10 +437,27 @@ void kmc_msd_scatter_kernel(const u64* __restrict__ khi, const u64* __restrict__
     if (r >= ctl->n_ranges) return;
     const u32 s = msd_seg_of(first, n_seg, r);
     if (seg_skip[s]) return;  // (block-uniform)
+    const int shift = msd_seg_shift(seg[s].hib);
+    const u32 mask = msd_seg_mask(seg[s].hib);
+    const bool sp = seg[s].parity != 0;  // from the segment's buffer into the other one
+    const u64* const khi = sp ? hi1 : hi0;
+    const u64* const klo = sp ? lo1 : lo0;
+    const u64* const kw = sp ? w1 : w0;
+    u64* const ohi = sp ? hi0 : hi1;
+    u64* const olo = sp ? lo0 : lo1;
+    u64* const ow = sp ? w0 : w1;
     for (u32 d = tid; d < KMC_MSD_NB; d += 1024) L.cur[d] = cbase[(size_t)s * KMC_MSD_NB + d] + hist[(size_t)r * KMC_MSD_NB + d];
     const u32 idx = r - first[s];
     const u32 b = seg[s].begin + idx * KMC_MSD_RANGE;
     const u32 n = min((u32)KMC_MSD_RANGE, seg[s].len - idx * KMC_MSD_RANGE);
+    // the keys of the first tile; every later tile is loaded while the one before it goes through LDS
+    u64 nlo[PER], nhi[PER], nw[PER];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const u32 i = tid + 1024u * e;
+        nlo[e] = 0; nhi[e] = 0; nw[e] = 0;
+        if (i < n) { nlo[e] = klo[b + i]; if (KW == 2) nhi[e] = khi[b + i]; if (WEIGHTS) nw[e] = kw[b + i]; }
+    }
     for (u32 t0 = 0; t0 < n; t0 += TILE) {
         const u32 tn = min((u32)TILE, n - t0);
         for (u32 d = tid; d < KMC_MSD_NB; d += 1024) L.cnt[d] = 0;
@@ -399,14 +467,18 @@ void kmc_msd_scatter_kernel(const u64* __restrict__ khi, const u64* __restrict__
         u32 md[PER], mr[PER];
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
-            const u32 i = t0 + tid + 1024u * e;
             md[e] = ~0u;
+            mlo[e] = nlo[e]; mhi[e] = nhi[e]; mw[e] = nw[e];
             if (tid + 1024u * e < tn) {
-                mlo[e] = klo[b + i];
-                mhi[e] = KW == 2 ? khi[b + i] : 0ull;
-                if (WEIGHTS) mw[e] = kw[b + i];
                 md[e] = (level0 && msd_is_filler<KW>(mhi[e], mlo[e], kb)) ? (u32)KMC_MSD_ND : (msd_bits<KW>(mhi[e], mlo[e], shift) & mask);
                 mr[e] = atomicAdd(&L.cnt[md[e]], 1u);
+            }
+        }
+        if (t0 + TILE < n) {  // (block-uniform) next tile's loads go out now and land during steps 2-4
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const u32 i = t0 + TILE + tid + 1024u * e;
+                if (i < n) { nlo[e] = klo[b + i]; if (KW == 2) nhi[e] = khi[b + i]; if (WEIGHTS) nw[e] = kw[b + i]; }
             }
         }
         __syncthreads();
@@ -466,17 +538,19 @@ __global__ void kmc_msd_order_kernel(const MsdTerm* __restrict__ term, u32 n_ter
     }
 }
 
+
 // ---- leaves ------------------------------------------------------------------------------------
 // One workgroup per terminal (in position order).  Result: the terminal's (key, count) pairs, sorted,
 // written at the terminal's own positions of the OTHER key buffer (dead there) and of t_cnt, and
 // nd[t] = their number.  kmc_msd_gather_kernel then makes the run dense.
 template <int KW, bool WEIGHTS> struct MsdLeafLds {
-    static constexpr int CAP = KW == 1 ? KMC_MSD_LEAF1 : KMC_MSD_LEAF2;
+    static constexpr int CAP = KW == 1 ? KMC_MSD_LEAF1 : (WEIGHTS ? KMC_MSD_LEAF2W : KMC_MSD_LEAF2);
     u64 a_lo[CAP], b_lo[CAP];
     u64 a_hi[KW == 2 ? CAP : 1], b_hi[KW == 2 ? CAP : 1];
     u64 a_w[WEIGHTS ? CAP : 1], b_w[WEIGHTS ? CAP : 1];   // weights (counts) of the keys
     u32 cnt[KMC_MSD_LEAF_NSB], off[KMC_MSD_LEAF_NSB + 1];
     u32 big[KMC_MSD_LEAF1 / KMC_MSD_THREAD_SORT + 4];     // sub-buckets too large for one thread
+    u32 woff[4][132];                                     // a wave's own offsets when it splits such a sub-bucket again (its counters: cnt)
     u32 nbig;
     u32 wsum[4];
     u32 bad;                  // a sub-bucket was too large for the in-wave rank sort
@@ -638,28 +712,24 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         }
     }
     __syncthreads();
-    // 3b. larger sub-buckets: rank sort by a wave (all-pairs, 64 keys of the bucket at a time), b -> a -> b
-    const u32 nbig = L.nbig;
-    for (u32 bi = wv; bi < nbig; bi += 4) {
-        const u32 d = L.big[bi];
-        const u32 o = L.off[d], m = L.off[d + 1] - o;
-        {   // heavily repeated keys: a sub-bucket that holds ONE key many times is sorted as it stands
-            const u64 plo = L.b_lo[o], phi = KW == 2 ? L.b_hi[o] : 0ull;
-            bool diff = false;
-            for (u32 i = lane; i < m; i += 64) diff |= L.b_lo[o + i] != plo || (KW == 2 && L.b_hi[o + i] != phi);
-            if (__builtin_amdgcn_ballot_w64(diff) == 0) continue;
-        }
-        if (m > 1024) { if (lane == 0) L.bad = 1; continue; }
+    // 3b. larger sub-buckets, one wave each.  Keys of real inputs cluster (families of k-mers that share
+    //     all but their last few bases sit in ONE sub-bucket while the leaf's range is set by the distance
+    //     between families), so a large sub-bucket is first split again by ITS OWN key range into 128
+    //     parts (wave-private counters), which the lanes insertion-sort; only what is still large after
+    //     that -- and not a single repeated key -- is rank-sorted all-pairs (64 keys at a time through
+    //     v_readlane).  Result back in b.
+    // all-pairs rank sort of m keys at s_*[0..m) into d_*[0..m)
+    auto allpairs = [&](const u64* s_lo, const u64* s_hi, const u64* s_w, u64* d_lo, u64* d_hi, u64* d_w, u32 m) {
         for (u32 c = 0; c < m; c += 64) {          // the chunk whose keys get their positions
             const u32 i = c + lane;
             u64 lo = 0, hi = 0, w = 0;
             const bool have = i < m;
-            if (have) { lo = L.b_lo[o + i]; if (KW == 2) hi = L.b_hi[o + i]; if (WEIGHTS) w = L.b_w[o + i]; }
+            if (have) { lo = s_lo[i]; if (KW == 2) hi = s_hi[i]; if (WEIGHTS) w = s_w[i]; }
             u32 rk = 0;
             for (u32 e = 0; e < m; e += 64) {      // against chunk e
                 const u32 j = e + lane;
                 u64 ql = ~0ull, qh = ~0ull;
-                if (j < m) { ql = L.b_lo[o + j]; qh = KW == 2 ? L.b_hi[o + j] : 0ull; }
+                if (j < m) { ql = s_lo[j]; qh = KW == 2 ? s_hi[j] : 0ull; }
                 const u32 mm = min(64u, m - e);
                 for (u32 x = 0; x < mm; ++x) {
                     const u64 ol = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(ql >> 32), (int)x) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)ql, (int)x);
@@ -670,12 +740,116 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
                     rk += (less || (eq && (e + x) < i)) ? 1u : 0u;
                 }
             }
-            if (have) { L.a_lo[o + rk] = lo; if (KW == 2) L.a_hi[o + rk] = hi; if (WEIGHTS) L.a_w[o + rk] = w; }
+            if (have) { d_lo[rk] = lo; if (KW == 2) d_hi[rk] = hi; if (WEIGHTS) d_w[rk] = w; }
         }
+    };
+    auto wave_sync = [&]() {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        for (u32 i = lane; i < m; i += 64) {       // back into b (this wave's own bucket)
+    };
+    const u32 nbig = L.nbig;
+    for (u32 bi = wv; bi < nbig; bi += 4) {
+        const u32 d = L.big[bi];
+        const u32 o = L.off[d], m = L.off[d + 1] - o;
+        // smallest / largest key of the sub-bucket
+        u64 mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
+        for (u32 i = lane; i < m; i += 64) {
+            const u64 lo = L.b_lo[o + i], hi = KW == 2 ? L.b_hi[o + i] : 0ull;
+            if (key_less(hi, lo, mnh, mnl)) { mnh = hi; mnl = lo; }
+            if (key_less(mxh, mxl, hi, lo)) { mxh = hi; mxl = lo; }
+        }
+#pragma unroll
+        for (int s2 = 32; s2 > 0; s2 >>= 1) {
+            const u64 oh = __shfl_xor(mnh, s2), ol = __shfl_xor(mnl, s2);
+            if (key_less(oh, ol, mnh, mnl)) { mnh = oh; mnl = ol; }
+            const u64 ph = __shfl_xor(mxh, s2), pl = __shfl_xor(mxl, s2);
+            if (key_less(mxh, mxl, ph, pl)) { mxh = ph; mxl = pl; }
+        }
+        if (mnh == mxh && mnl == mxl) continue;  // ONE key many times: sorted as it stands
+        const u64 rl2 = mxl - mnl, rh2 = mxh - mnh - (mxl < mnl ? 1ull : 0ull);
+        const int top2 = rh2 ? 127 - __clzll((long long)rh2) : 63 - __clzll((long long)rl2);
+        const int sh2 = top2 >= 7 ? top2 - 6 : 0;
+        auto bkt2 = [&](u64 hi, u64 lo) -> u32 {
+            const u64 dl = lo - mnl;
+            if (KW == 1) return (u32)(dl >> sh2) & 127u;
+            const u64 dh = hi - mnh - (lo < mnl ? 1ull : 0ull);
+            if (sh2 >= 64) return (u32)(dh >> (sh2 - 64)) & 127u;
+            if (sh2 == 0) return (u32)dl & 127u;
+            return (u32)((dl >> sh2) | (dh << (64 - sh2))) & 127u;
+        };
+        u32* const wc = &L.cnt[wv * 128];   // (the leaf's own cursors are dead by now)
+        u32* const wo = L.woff[wv];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) wc[lane * 2 + e] = 0;
+        wave_sync();
+        for (u32 i = lane; i < m; i += 64) atomicAdd(&wc[bkt2(KW == 2 ? L.b_hi[o + i] : 0ull, L.b_lo[o + i])], 1u);
+        wave_sync();
+        {
+            u32 c4[2], mine = 0;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { c4[e] = wc[lane * 2 + e]; mine += c4[e]; }
+            u32 inc = mine;
+#pragma unroll
+            for (int s2 = 1; s2 < 64; s2 <<= 1) { const u32 v = __shfl_up(inc, s2); if ((int)lane >= s2) inc += v; }
+            u32 run = inc - mine;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) { wo[lane * 2 + e] = run; wc[lane * 2 + e] = run; run += c4[e]; }
+            if (lane == 63) wo[128] = run;
+        }
+        wave_sync();
+        for (u32 i = lane; i < m; i += 64) {
+            const u64 lo = L.b_lo[o + i], hi = KW == 2 ? L.b_hi[o + i] : 0ull;
+            const u32 pp = atomicAdd(&wc[bkt2(hi, lo)], 1u);
+            L.a_lo[o + pp] = lo;
+            if (KW == 2) L.a_hi[o + pp] = hi;
+            if (WEIGHTS) L.a_w[o + pp] = L.b_w[o + i];
+        }
+        wave_sync();
+        // every lane: its two parts, insertion sort in a; parts that are still large are left for the wave
+        u32 big_mask = 0;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const u32 oo = o + wo[lane * 2 + e], mm = wo[lane * 2 + e + 1] - wo[lane * 2 + e];
+            if (mm > KMC_MSD_THREAD_SORT) { big_mask |= 1u << e; continue; }
+            for (u32 i = 1; i < mm; ++i) {
+                const u64 lo = L.a_lo[oo + i], hi = KW == 2 ? L.a_hi[oo + i] : 0ull;
+                u64 w = 0;
+                if (WEIGHTS) w = L.a_w[oo + i];
+                u32 j = i;
+                while (j > 0) {
+                    const u64 pl = L.a_lo[oo + j - 1], ph = KW == 2 ? L.a_hi[oo + j - 1] : 0ull;
+                    if (!key_less(hi, lo, ph, pl)) break;
+                    L.a_lo[oo + j] = pl;
+                    if (KW == 2) L.a_hi[oo + j] = ph;
+                    if (WEIGHTS) L.a_w[oo + j] = L.a_w[oo + j - 1];
+                    --j;
+                }
+                if (j != i) { L.a_lo[oo + j] = lo; if (KW == 2) L.a_hi[oo + j] = hi; if (WEIGHTS) L.a_w[oo + j] = w; }
+            }
+        }
+        wave_sync();
+        // parts that are still large: one repeated key (nothing to do), or all-pairs a -> b -> a
+        unsigned long long todo;
+        while ((todo = __builtin_amdgcn_ballot_w64(big_mask != 0)) != 0) {
+            const int src_lane = (int)__builtin_ctzll(todo);
+            const u32 bm = (u32)__builtin_amdgcn_readlane((int)big_mask, src_lane);
+            const int e = __ffs((int)bm) - 1;
+            const u32 oo = o + wo[src_lane * 2 + e];
+            const u32 mm = wo[src_lane * 2 + e + 1] - wo[src_lane * 2 + e];
+            if ((int)lane == src_lane) big_mask &= ~(1u << e);
+            const u64 plo = L.a_lo[oo], phi = KW == 2 ? L.a_hi[oo] : 0ull;
+            bool diff = false;
+            for (u32 i = lane; i < mm; i += 64) diff |= L.a_lo[oo + i] != plo || (KW == 2 && L.a_hi[oo + i] != phi);
+            if (__builtin_amdgcn_ballot_w64(diff) == 0) continue;
+            if (mm > 1024) { if (lane == 0) L.bad = 1; continue; }
+            allpairs(&L.a_lo[oo], KW == 2 ? &L.a_hi[oo] : nullptr, WEIGHTS ? &L.a_w[oo] : nullptr,
+                     &L.b_lo[oo], KW == 2 ? &L.b_hi[oo] : nullptr, WEIGHTS ? &L.b_w[oo] : nullptr, mm);
+            wave_sync();
+            for (u32 i = lane; i < mm; i += 64) { L.a_lo[oo + i] = L.b_lo[oo + i]; if (KW == 2) L.a_hi[oo + i] = L.b_hi[oo + i]; if (WEIGHTS) L.a_w[oo + i] = L.b_w[oo + i]; }
+            wave_sync();
+        }
+        for (u32 i = lane; i < m; i += 64) {       // back into b (this wave's own sub-bucket)
             L.b_lo[o + i] = L.a_lo[o + i];
             if (KW == 2) L.b_hi[o + i] = L.a_hi[o + i];
             if (WEIGHTS) L.b_w[o + i] = L.a_w[o + i];

@@ -1,4 +1,4 @@
-// kmc_stream.cuh -- KMC_ALGO_STREAM: the general counting kernel (any read lengths, any bytes).
+// kmc_stream.hip.h -- KMC_ALGO_STREAM: the general counting kernel (any read lengths, any bytes).
 //
 // Replaces the reference's window loop + grouping, k-mer-count/src/main.rs:63-87, for
 // contiguous k.
@@ -19,7 +19,7 @@
 // ds_add count); keys that do not fit go straight to the global table with device-scope
 // atomics; at the end the LDS table is flushed with one global atomic per distinct key.
 #pragma once
-#include "kmc_device.cuh"
+#include "kmc_device.hip.h"
 
 #define KMC_STREAM_THREADS 1024
 #define KMC_STREAM_WAVES (KMC_STREAM_THREADS / 64)

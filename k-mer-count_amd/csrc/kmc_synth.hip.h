@@ -1,4 +1,4 @@
-// kmc_synth.cuh -- seeded, size-parameterised re-creation of the input distribution of the
+// kmc_synth.hip.h -- seeded, size-parameterised re-creation of the input distribution of the
 // reference's generator, /root/reference/random_fasta_generator.py:5-15: a pool of `pool`
 // uniform-random ACGT lines of `line_len` bases (:5-8); record i (1-based) has header
 // ">dummy_sequence_{i:03d} {i}th record" (:11-12) and `lines_per_record` lines, each drawn

@@ -1,31 +1,41 @@
-// kmc_table.cuh -- maintenance kernels of the global count table: the GPU side of the
+// kmc_table.hip.h -- maintenance kernels of the global count table: the GPU side of the
 // reference's grouping/ordering step (k-mer-count/src/main.rs:84,87): compaction of occupied
 // slots, rehash on growth, merging (key,count) pairs (spill drain, multi-GPU reduce), owner
 // partition for the all-to-all, and small utilities.
 #pragma once
-#include "kmc_device.cuh"
+#include "kmc_device.hip.h"
 
-// occupied slots -> dense (hi, lo, cnt) arrays, plus the identity permutation for the sort and the
-// sum of all counts (counters[KMC_CTR_SUM]) in the same pass
+// occupied slots -> dense (hi, lo, cnt) arrays (+ the identity permutation when asked for) and the sum of
+// all counts (counters[KMC_CTR_SUM]) in the same launch.  Every WAVE owns a contiguous span of slots: it
+// counts its occupied slots first, reserves their output range with ONE returning atomic, then copies.
+// (One atomic per entry -- and later one per 64 slots -- on the same counter cost 70 ms and 12 ms on a
+// 64 M-slot table with 21 M entries; the span form needs 8192 atomics whatever the table.)
 template <int KW>
-__global__ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_cnt, u64* out_idx, int parity) {
+__global__ __launch_bounds__(256)
+void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_cnt, u64* out_idx, int parity) {
     const u64 cap = g.capmask + 1;
     const int c_out = parity ? KMC_CTR_OUT1 : KMC_CTR_OUT, c_sum = parity ? KMC_CTR_SUM1 : KMC_CTR_SUM;
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // clear the pair the NEXT finalize will use
         g.counters[parity ? KMC_CTR_OUT : KMC_CTR_OUT1] = 0;
         g.counters[parity ? KMC_CTR_SUM : KMC_CTR_SUM1] = 0;
     }
+    const u32 lane = threadIdx.x & 63;
+    const u64 n_waves = (u64)gridDim.x * (blockDim.x >> 6), wave = (u64)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const u64 span = ((cap + n_waves - 1) / n_waves + 63) & ~63ull;
+    const u64 s0 = wave * span, s1 = min(s0 + span, cap);
+    u64 total = 0;
+    for (u64 s = s0 + lane; (s - lane) < s1; s += 64) {
+        const bool occ = s < s1 && ((KW == 1) ? (g.key_lo[s] != KMC_EMPTY64) : (g.key_hi[s] != KMC_EMPTY64));
+        total += (u64)__popcll(__builtin_amdgcn_ballot_w64(occ));
+    }
+    if (total == 0) return;  // (wave-uniform)
+    unsigned long long base = 0;
+    if (lane == 0) base = atomicAdd((unsigned long long*)&g.counters[c_out], (unsigned long long)total);
+    base = ((unsigned long long)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(base >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)base);
     u64 sum = 0;
-    const u64 cap_round = (cap + 63) & ~63ull;  // whole waves run every trip: the slot reservation below is wave-wide
-    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap_round; s += (u64)gridDim.x * blockDim.x) {
-        const bool occ = s < cap && ((KW == 1) ? (g.key_lo[s] != KMC_EMPTY64) : (g.key_hi[s] != KMC_EMPTY64));
-        // one returning atomic per wave (not per entry: 21 M adds to ONE address took 70 ms on a 64 M-slot table)
+    for (u64 s = s0 + lane; (s - lane) < s1; s += 64) {
+        const bool occ = s < s1 && ((KW == 1) ? (g.key_lo[s] != KMC_EMPTY64) : (g.key_hi[s] != KMC_EMPTY64));
         const unsigned long long m = __builtin_amdgcn_ballot_w64(occ);
-        if (m == 0) continue;
-        unsigned long long base = 0;
-        const int leader = (int)__builtin_ctzll(m);
-        if ((int)(threadIdx.x & 63) == leader) base = atomicAdd((unsigned long long*)&g.counters[c_out], (unsigned long long)__popcll(m));
-        base = ((unsigned long long)(u32)__builtin_amdgcn_readlane((int)(u32)(base >> 32), leader) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)base, leader);
         if (occ) {
             const u64 idx = base + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
             if (KW == 2) out_hi[idx] = g.key_hi[s];
@@ -35,9 +45,10 @@ __global__ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_
             if (out_idx) out_idx[idx] = idx;
             sum += c;
         }
+        base += (unsigned long long)__popcll(m);
     }
     sum = wave_sum_u64(sum);
-    if ((threadIdx.x & 63) == 0 && sum) atomicAdd((unsigned long long*)&g.counters[c_sum], sum);
+    if (lane == 0 && sum) atomicAdd((unsigned long long*)&g.counters[c_sum], sum);
 }
 
 // kmc_reset in one launch: every slot empty, every counter zero

@@ -1,4 +1,4 @@
-// kmc_walk.cuh -- KMC_ALGO_WALK: memoised successor walk for batches of short reads.
+// kmc_walk.hip.h -- KMC_ALGO_WALK: memoised successor walk for batches of short reads.
 //
 // Replaces the reference's window loop + grouping (k-mer-count/src/main.rs:63-87) for
 // contiguous k, exactly (same table as KMC_ALGO_STREAM and the CPU oracle), with ONE LDS lookup
@@ -34,7 +34,7 @@
 // peak.
 #pragma once
 #include "../../include/kmc.h"
-#include "kmc_device.cuh"
+#include "kmc_device.hip.h"
 
 #define KMC_WALK_MAX_K 63
 #define KMC_WALK_MAX_READ 416
@@ -183,7 +183,7 @@ __device__ __forceinline__ u64 walk_roll(const GTable& g, WCtx& ctx, u32& depth,
 }
 
 // find-or-insert a node key; returns its id (>= 1) or 0 when the node table is full.
-// Same wave-uniform loop shape as gtable_add (kmc_device.cuh).
+// Same wave-uniform loop shape as gtable_add (kmc_device.hip.h).
 template <int KW>
 __device__ __forceinline__ u32 walk_node(WalkLds<KW>& L, WCtx nk) {
     u32 h = (u32)(kmc_hash_key<KW>(nk.hi, nk.lo) >> (64 - KMC_WALK_NLOG));
@@ -923,11 +923,22 @@ static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const u
         static_assert(((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE) % 256 == 0 && 256 % KMC_WALK_STRIDE == 0, "unfold grid must cover the items exactly");
         hipLaunchKernelGGL((kmc_walk_unfold_kernel<KW, CANON>), dim3((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE / 256), dim3(256), 0, st,
                            (const WalkMemoSlot<KW>*)&slots[parity], gcnt, hdr, k, g);
-        if (sk.key_lo) {
-            hipLaunchKernelGGL((kmc_sk_unfold_kernel<KW, CANON>), dim3((unsigned)n_cu * 8), dim3(256), 0, st, sk, k, g);
-            hipLaunchKernelGGL(kmc_sk_spill_reset_kernel, dim3(1), dim3(64), 0, st, sk);
-        }
     }
+}
+
+// The (k+16)-mer table is unfolded ONCE per batch, after the batch's last walk launch (its counts add up
+// over the launches): with one unfold per launch a 27-launch batch walked its 3 M entries 27 times.
+static inline int kmc_sk_unfold_launch(hipStream_t st, int n_cu, int KW, int k, bool canon, GTable sk, GTable g) {
+    if (!sk.key_lo) return KMC_OK;
+    if (KW == 1) {
+        if (canon) hipLaunchKernelGGL((kmc_sk_unfold_kernel<1, true>), dim3((unsigned)n_cu * 8), dim3(256), 0, st, sk, k, g);
+        else hipLaunchKernelGGL((kmc_sk_unfold_kernel<1, false>), dim3((unsigned)n_cu * 8), dim3(256), 0, st, sk, k, g);
+    } else {
+        if (canon) hipLaunchKernelGGL((kmc_sk_unfold_kernel<2, true>), dim3((unsigned)n_cu * 8), dim3(256), 0, st, sk, k, g);
+        else hipLaunchKernelGGL((kmc_sk_unfold_kernel<2, false>), dim3((unsigned)n_cu * 8), dim3(256), 0, st, sk, k, g);
+    }
+    hipLaunchKernelGGL(kmc_sk_spill_reset_kernel, dim3(1), dim3(64), 0, st, sk);
+    return hipGetLastError() == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
 
 // phase 0: the walk kernel over tiles [tile_begin, tile_end); phase 1: the scalar kernel for the reads

@@ -35,7 +35,7 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def owner_np(key_hi: np.ndarray, key_lo: np.ndarray, n_parts: int) -> np.ndarray:
-    """Vectorised kmc_owner_of (same arithmetic as kmc_table.cuh:kmc_owner)."""
+    """Vectorised kmc_owner_of (same arithmetic as kmc_table.hip.h:kmc_owner)."""
     with np.errstate(over="ignore"):
         z = key_lo.astype(np.uint64) ^ (key_hi.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15))
         z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)

@@ -15,7 +15,7 @@ line pairs INSIDE a record are (p, q).  U and A are histograms over all records 
 P*(LL-k+1) + P*P*(k-1) windows (3,500 at k=31).  The result is the exact canonical (or forward)
 table of the whole range -- what `count >= count-of-a-prefix` could only bound.
 
-This file restates the generator's arithmetic (csrc/kmc_synth.cuh: counter-based splitmix64) in
+This file restates the generator's arithmetic (csrc/kmc_synth.hip.h: counter-based splitmix64) in
 numpy / pure Python on purpose: it shares no code with libkmc, the HIP kernels or oracle/kmc_oracle.c.
 tests/test_properties_cpu.py validates it against the C oracle counting the bytes that libkmc's host
 generator produces (200 k records), which pins both the restated generator and the expansion.

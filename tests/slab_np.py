@@ -1,5 +1,5 @@
 """Test-side numpy restatement of the slab layout of the multi-GPU reduce
-(k-mer-count_amd/csrc/kmc_table.cuh: kmc_pack_slab_kernel / kmc_merge_slabs_kernel) and a CPU
+(k-mer-count_amd/csrc/kmc_table.hip.h: kmc_pack_slab_kernel / kmc_merge_slabs_kernel) and a CPU
 stand-in for a kmc ctx that speaks the same protocol, so that distributed.reduce_tables can be
 driven by world_size-2 gloo processes without a GPU.  Test infrastructure only."""
 import ctypes as C

@@ -894,7 +894,7 @@ def test_auto_hands_over_long_high_cardinality_reads(kmc, oracle):
 
 @pytest.mark.parametrize("k,pool,n_rec", [(31, 0, 100_000), (63, 0, 60_000), (31, 1000, 150_000), (21, 40, 100_000), (5, 0, 50_000), (33, 200, 80_000)])
 def test_msd_sort_path_matches_oracle(kmc, oracle, k, pool, n_rec):
-    """KMC_ALGO_SORT = extraction + the hand-written MSD radix sort + run-length (kmc_msd.cuh), on inputs
+    """KMC_ALGO_SORT = extraction + the hand-written MSD radix sort + run-length (kmc_msd.hip.h), on inputs
     from all-distinct (pool 0) to heavily repeated keys (small pools: equal-key segments, merged
     leaves, sub-buckets larger than a wave), one- and two-word keys, both strands: the oracle's table."""
     s = kmc.Synth(seed=11, pool=pool)

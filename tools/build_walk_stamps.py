@@ -5,7 +5,7 @@ in a __device__ array of its own plus kmc_debug_walk_stamps() to fetch them.  Th
 never contains any of this."""
 import os, subprocess, sys, tempfile, shutil
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-s=open(os.path.join(ROOT, 'k-mer-count_amd', 'csrc', 'kmc_walk.cuh')).read()
+s=open(os.path.join(ROOT, 'k-mer-count_amd', 'csrc', 'kmc_walk.hip.h')).read()
 def rep(old,new):
     global s
     assert old in s, old[:60]; s=s.replace(old,new,1)
@@ -54,7 +54,7 @@ os.makedirs(os.path.join(w, 'pkg', 'csrc')); os.makedirs(os.path.join(w, 'includ
 for f in os.listdir(os.path.join(ROOT, 'k-mer-count_amd', 'csrc')):
     shutil.copy(os.path.join(ROOT, 'k-mer-count_amd', 'csrc', f), os.path.join(w, 'pkg', 'csrc', f))
 shutil.copy(os.path.join(ROOT, 'include', 'kmc.h'), os.path.join(w, 'include', 'kmc.h'))
-open(os.path.join(w, 'pkg', 'csrc', 'kmc_walk.cuh'), 'w').write(walk_src)
+open(os.path.join(w, 'pkg', 'csrc', 'kmc_walk.hip.h'), 'w').write(walk_src)
 open(os.path.join(w, 'pkg', 'csrc', 'kmc_api.hip'), 'w').write(src)
 out = os.path.join(ROOT, 'k-mer-count_amd', 'libkmc_wstamps.so')
 subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '-fPIC', '--offload-arch=gfx950', '-Wno-unused-function', '-I../include', '-c', 'csrc/kmc_api.hip', '-o', 'kmc_api.o'], cwd=os.path.join(w, 'pkg'), check=True)

@@ -53,3 +53,9 @@ except Exception as e: print("lr unreadable", e)
 for f in glob.glob("gpurun_out/prof_${tag}_lr/*/*_kernel_stats.csv")[:1]:
     for r in list(csv.DictReader(open(f)))[:10]: print(r["Name"][:52].ljust(52), r["Calls"].rjust(4), round(float(r["AverageNs"])/1e6,3), r["Percentage"])
 P
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_fin -- python3 tools/measure_finalize.py > gpurun_out/${tag}_fin.txt 2> gpurun_out/${tag}_fin.err; echo "fin rc=$?"; cat gpurun_out/${tag}_fin.txt
+python3 - <<P
+import csv,glob
+for f in glob.glob("gpurun_out/prof_${tag}_fin/*/*_kernel_stats.csv")[:1]:
+    for r in list(csv.DictReader(open(f)))[:8]: print(r["Name"][:52].ljust(52), r["Calls"].rjust(4), round(float(r["AverageNs"])/1e6,3), r["Percentage"])
+P
