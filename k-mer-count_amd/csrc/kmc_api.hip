@@ -77,6 +77,7 @@ struct kmc_ctx {
     bool walk_ws_clean = false;  // workspace header + dense counters are zero (left so by kmc_walk_unfold_kernel)
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
     DevBuf s_lo[2], s_hi[2];
+    DevBuf lr_rank;  // LR mode: rank of every position's 27-mer among the batch's distinct 27-mers
     // hand-written MSD radix sort (kmc_msd.hip.h): per-range histograms, segment lists, terminals
     DevBuf m_hist, m_stot, m_bsum, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_cnt, m_w[2];
     MsdCtl* h_ctl = nullptr;  // pinned mirror of the sort's device counters
@@ -498,10 +499,12 @@ int launch_extract(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64
 // once), dropping all-ones filler keys, and appends the resulting sorted (key, count) run to c->runs.
 // lo[1] / hi[1] / w[1] are scratch of the same size.  One host synchronisation per level (the number
 // of segments that go on) and one for the size of the run.
-int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w[2], u64 n, unsigned kb) {
+// KW: words per key (1: lo only).  out == nullptr: the run joins c->runs; otherwise it is handed to the
+// caller (n == 0 when nothing but filler came in).
+int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w[2], u64 n, unsigned kb, int KW, kmc_ctx::Run* out = nullptr) {
+    if (out) *out = kmc_ctx::Run{};
     if (!n) return KMC_OK;
     if (n >= (1ull << 32) - KMC_MSD_RANGE) return fail(c, KMC_ERR_ARG, "msd sort: more than 2^32 keys in one pass");
-    const int KW = c->KW;
     const bool weights = w[0] != nullptr;
     const u32 leaf_cap = KW == 1 ? KMC_MSD_LEAF1 : (w[0] ? KMC_MSD_LEAF2W : KMC_MSD_LEAF2);
     const u64 max_seg = n / leaf_cap + 257;
@@ -611,13 +614,14 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     run.n = n_pairs;
     run.total = weights ? (u64)c->h_ctl->w_total : (u64)c->h_ctl->n_valid;  // what the run's counts sum to
     run.total_known = true;
-    c->runs.push_back(run);
     if (KW == 1) hipLaunchKernelGGL(kmc_msd_gather_kernel<1>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, (const u32*)c->m_nd.p, (const u32*)c->m_base.p,
                                     (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1], (const u64*)t_cnt0, run.hi, run.lo, run.cnt);
     else hipLaunchKernelGGL(kmc_msd_gather_kernel<2>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, (const u32*)c->m_nd.p, (const u32*)c->m_base.p,
                             (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1], (const u64*)t_cnt0, run.hi, run.lo, run.cnt);
-    HIPCHK(c, hipGetLastError());
-    if (!n_pairs) { c->run_pool.push_back(c->runs.back()); c->runs.pop_back(); }
+    if (hipGetLastError() != hipSuccess) { c->run_pool.push_back(run); return fail(c, KMC_ERR_HIP, "msd sort: gather launch failed"); }
+    if (out) *out = run;
+    else if (n_pairs) c->runs.push_back(run);
+    else c->run_pool.push_back(run);
     return KMC_OK;
 }
 
@@ -642,7 +646,7 @@ int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
         u64* const khi[2] = {(u64*)c->s_hi[0].p, (u64*)c->s_hi[1].p};
         u64* const klo[2] = {(u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p};
         u64* const kwt[2] = {nullptr, nullptr};
-        rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen);
+        rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen, c->KW);
         if (rc) return rc;
         rc = launch_end(c);
         if (rc) return rc;
@@ -877,29 +881,58 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
         const bool lr = c->cfg.mode == KMC_MODE_LR;
         if (lr) {
             // Reference mode (main.rs:63-81): every window start contributes up to 61 keys (27 + gap + 27 for
-            // sizes 80..=140), and almost every key is new (1.08 M distinct of 3.55 M on the fixture): the
-            // keys are FORMED by kmc_lr_extract_kernel and grouped by the radix sort + run-length, like the
-            // reference's own push + sort() (main.rs:79,87) -- no hash table, no per-occurrence atomics.
-            // Sub-batches of 2^25 window starts (61 x 16 B x 2 buffers = 64 GiB of keys in flight at most).
+            // sizes 80..=140), and almost every key is new (1.08 M distinct of 3.55 M on the fixture): the keys
+            // are FORMED and grouped by the radix sort + run-length, like the reference's own push + sort()
+            // (main.rs:79,87) -- no hash table, no per-occurrence atomics -- as pairs of 27-mer ranks
+            // (kmc_lr.hip.h): sort the batch's 27-mers once, then sort one-word rank pairs.
+            // Sub-batches of 2^25 window starts (61 x 8 B x 2 buffers = 32 GiB of keys in flight at most).
             const u64 per = KMC_LRX_NS;
             const u64 SB = 1ull << 25;
             for (u64 p0 = 0; p0 < n_bases; p0 += SB) {
                 const u64 p1 = std::min(n_bases, p0 + SB);
                 const u64 n = (p1 - p0) * per;
+                const u64 q0 = p0, q1 = std::min(n_bases, p1 + KMC_LRX_DMAX);
+                const u64 nq = q1 - q0;
                 for (int i = 0; i < 2; ++i) {
-                    rc = ensure(c, c->s_lo[i], (size_t)n * sizeof(u64)); if (rc) return rc;
-                    rc = ensure(c, c->s_hi[i], (size_t)n * sizeof(u64)); if (rc) return rc;
+                    rc = ensure(c, c->s_lo[i], (size_t)std::max(n, nq) * sizeof(u64)); if (rc) return rc;
                 }
+                rc = ensure(c, c->lr_rank, (size_t)nq * sizeof(u32)); if (rc) return rc;
                 rc = launch_begin(c);
                 if (rc) return rc;
-                hipLaunchKernelGGL(kmc_lr_extract_kernel, dim3((unsigned)((p1 - p0 + KMC_LRX_POS - 1) / KMC_LRX_POS)), dim3(KMC_LRX_THREADS), 0, c->stream,
-                                   d_bases, n_bases, d_offsets, n_reads, p0, p1, (u64*)c->s_hi[0].p, (u64*)c->s_lo[0].p, c->d_counters);
-                HIPCHK(c, hipGetLastError());
                 u64* const khi[2] = {(u64*)c->s_hi[0].p, (u64*)c->s_hi[1].p};
                 u64* const klo[2] = {(u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p};
                 u64* const kwt[2] = {nullptr, nullptr};
-                rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen);
+                // 1. the batch's distinct 27-mers, ordered: the dictionary
+                const unsigned mer_grid = (unsigned)((nq + KMC_LRX_POS - 1) / KMC_LRX_POS);
+                hipLaunchKernelGGL(kmc_lr_mer_kernel<0>, dim3(mer_grid), dim3(KMC_LRX_THREADS), 0, c->stream,
+                                   d_bases, n_bases, q0, q1, klo[0], (const u64*)nullptr, 0u, (u32*)nullptr);
+                HIPCHK(c, hipGetLastError());
+                kmc_ctx::Run mers;
+                rc = msd_sort_to_run(c, khi, klo, kwt, nq, 2u * KMC_LR_L, 1, &mers);
                 if (rc) return rc;
+                const u64 n_distinct = mers.n;
+                if (n_distinct) {  // 2. every position's rank in it
+                    hipLaunchKernelGGL(kmc_lr_mer_kernel<1>, dim3(mer_grid), dim3(KMC_LRX_THREADS), 0, c->stream,
+                                       d_bases, n_bases, q0, q1, (u64*)nullptr, (const u64*)mers.lo, (u32)n_distinct, (u32*)c->lr_rank.p);
+                    HIPCHK(c, hipGetLastError());
+                }
+                if (n_distinct) {
+                    // 3. every key as a pair of ranks, sorted and run-length counted; 4. back to 108-bit keys
+                    int B = 1;
+                    while ((1ull << B) < n_distinct) ++B;
+                    hipLaunchKernelGGL(kmc_lr_pair_kernel, dim3((unsigned)((p1 - p0 + KMC_LRX_POS - 1) / KMC_LRX_POS)), dim3(KMC_LRX_THREADS), 0, c->stream,
+                                       d_offsets, n_reads, p0, p1, q0, nq, (const u32*)c->lr_rank.p, B, klo[0], c->d_counters);
+                    HIPCHK(c, hipGetLastError());
+                    kmc_ctx::Run run;
+                    rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)B, 1, &run);
+                    if (rc) { c->run_pool.push_back(mers); return rc; }
+                    if (run.n) {
+                        hipLaunchKernelGGL(kmc_lr_compose_kernel, dim3(grid_for(c, run.n, 256)), dim3(256), 0, c->stream, run.hi, run.lo, run.n, (const u64*)mers.lo, B);
+                        HIPCHK(c, hipGetLastError());
+                        c->runs.push_back(run);
+                    } else if (run.lo) c->run_pool.push_back(run);
+                }
+                if (mers.lo) c->run_pool.push_back(mers);  // (stream order: the compose kernel is queued before any later use)
                 rc = launch_end(c);
                 if (rc) return rc;
                 c->pending = true;
@@ -1118,7 +1151,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     if (c->spill_cnt) (void)hipFree(c->spill_cnt);
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
                       &c->t_idx0, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo, &c->vr_reads, &c->vr_cnt, &c->vr_pos,
-                      &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1],
+                      &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->lr_rank,
                       &c->m_hist, &c->m_stot, &c->m_bsum, &c->m_rmin, &c->m_rmax, &c->m_seg[0], &c->m_seg[1], &c->m_first, &c->m_cbase, &c->m_skip, &c->m_term, &c->m_ord,
                       &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_cnt, &c->m_w[0], &c->m_w[1],
                       &c->snap_hi, &c->snap_lo, &c->snap_cnt, &c->snap_n, &c->snap_occ, &c->rx_hi, &c->rx_lo, &c->rx_cnt};
@@ -1355,7 +1388,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         u64* const klo[2] = {(u64*)c->t_lo.p, (u64*)c->o_lo.p};
         u64* const kwt[2] = {(u64*)c->t_cnt.p, (u64*)c->o_cnt.p};
         const size_t before = c->runs.size();
-        rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen);
+        rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen, c->KW);
         if (rc) return rc;
         if (c->runs.size() > before) {
             c->view_run = c->runs.back();   // the merged view is not one of the ctx's runs (they stay as they are)

@@ -21,24 +21,32 @@
 
 __device__ __forceinline__ int kmc_code_of(uint8_t b) { return b == 'A' ? 0 : b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : -1; }
 
-// ---- LR mode as a throughput path: extraction for the sort pipeline -----------------------------------
-// This kernel only FORMS the keys -- what main.rs:76-79 does with slices and a String -- and the hand-written
-// radix sort + run-length (kmc_msd.hip.h) does the grouping, as main.rs:87 does with sort().
-//
-// One thread per (window start, chunk size) pair, so stores are fully coalesced: key q = 61 * (p - p_begin)
-// + (s - 80).  A workgroup of 256 threads covers KMC_LRX_POS = 256 consecutive window starts (15,616 keys):
-// their bases (plus the 140 that follow) are packed once into LDS at 2 bits per base, MSB first, and every
-// key is two funnel shifts out of that stream (no per-base loop).  Pairs that do not exist (read too short
-// for this size, window start in the last 79 bases of a read) get the all-ones filler the sort drops.
-// (The first version covered 64 window starts with 1024 threads and had thread 0 find the first read by
-// binary search before anything else could start: 25 k workgroups of mostly latency, 4.4 ms for 71 M keys
-// = 260 GB/s of stores.  Now every thread finds the read of its own window start.)
-// A non-ACGT byte inside an emitted chunk raises error bit 4 (main.rs:23).
+// ---- LR mode as a throughput path: keys as pairs of 27-mer RANKS ----------------------------------------
+// A key is (27-mer at p, 27-mer at p + d) with d = s - 27 in 53..=113, so every key of a batch is a pair of
+// 27-mers of the SAME batch, and a batch of n bases has at most n distinct 27-mers.  Therefore:
+//   1. kmc_lr_mer_kernel<0> the 27-mer at every base position (54 bits, one word); the MSD sort + run-length
+//                           (kmc_msd.hip.h) turns the n of them into the sorted list of DISTINCT 27-mers of
+//                           the batch: the dictionary, dict[rank] = 27-mer;
+//   2. kmc_lr_mer_kernel<1> rank[q] = position of the 27-mer at q in the dictionary (binary search).  Rank
+//                           order = string order (2 bits per base, MSB first);
+//   3. kmc_lr_pair_kernel   every key of main.rs:76-79 as ONE word (rank[p] << B) | rank[p + d], B = bits of
+//                           the number of distinct 27-mers: 2B <= 2 * log2(n) bits instead of 108, spread
+//                           evenly over their range -- what the MSD sort + run-length likes best: two levels
+//                           of one-word keys for 71 M keys where the 108-bit keys took five levels of two-word
+//                           keys (all 61 keys of a window start share their first 54 bits);
+//   4. kmc_lr_compose_kernel  (key, count) pairs of the sorted run back to 108-bit keys through the dictionary.
+// The order of the pairs of ranks is the order of the pairs of 27-mers, i.e. of the reference's strings
+// (main.rs:87), so the result is the same sorted (key, count) run as before; sort() + "equal lines" of the
+// reference = MSD sort + run-length here, on keys a quarter of the size.
+// A non-ACGT byte inside an emitted chunk raises error bit 4 (main.rs:23): its 27-mers get no rank.
 #define KMC_LRX_POS 256
 #define KMC_LRX_THREADS 256
 #define KMC_LRX_NS (KMC_LR_SMAX - KMC_LR_SMIN + 1)   // 61 chunk sizes
-#define KMC_LRX_SPAN (KMC_LRX_POS + KMC_LR_SMAX)     // bases a workgroup looks at
+#define KMC_LRX_DMIN (KMC_LR_SMIN - KMC_LR_R)        // 53: distance of the right 27-mer, smallest
+#define KMC_LRX_DMAX (KMC_LR_SMAX - KMC_LR_R)        // 113: largest
+#define KMC_LRX_SPAN (KMC_LRX_POS + 32)              // bases a workgroup of kmc_lr_mer_kernel looks at
 #define KMC_LRX_WORDS ((KMC_LRX_SPAN + 15) / 16 + 3)
+#define KMC_LR_NORANK 0xFFFFFFFFu
 
 // 64-bit window of a big-endian 2-bit stream (w[i] holds bases 16i.., first base in the top bits)
 // starting at base `a`: the 32 bases a .. a+31
@@ -54,30 +62,62 @@ __device__ __forceinline__ u32 lrx_badwin(const u32* b, u32 a) {
     return o ? ((b[i] << o) | (b[i + 1] >> (32 - o))) : b[i];
 }
 
+// 1. / 2. positions [q0, q1), M = the 27-mer at q (all-ones filler where fewer than 27 bases follow or one of
+//    them is not ACGT).  MODE 0: out_lo[q - q0] = M, the keys of the dictionary sort (one word, 54 bits).
+//    MODE 1: rank[q - q0] = index of M in the sorted dictionary (binary search, log2(n_dict) probes of an
+//    array that sits in L2), KMC_LR_NORANK for the filler.  A workgroup packs its 256 + 26 bases into LDS at
+//    2 bits per base once; every 27-mer is one funnel shift out of it.
+template <int MODE>
 __global__ __launch_bounds__(KMC_LRX_THREADS)
-void kmc_lr_extract_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets, u64 n_reads,
-                           u64 p_begin, u64 p_end, u64* __restrict__ out_hi, u64* __restrict__ out_lo, u64* __restrict__ counters) {
-    __shared__ u32 w[KMC_LRX_WORDS];          // 2-bit codes
-    __shared__ u32 bad[KMC_LRX_WORDS / 2 + 2]; // 1 bit per base
-    __shared__ u64 rend[KMC_LRX_POS];          // end of the read a window start lies in
+void kmc_lr_mer_kernel(const uint8_t* __restrict__ bases, u64 n_bases, u64 q0, u64 q1, u64* __restrict__ out_lo,
+                       const u64* __restrict__ dict, u32 n_dict, u32* __restrict__ rank) {
+    __shared__ u32 w[KMC_LRX_WORDS];
+    __shared__ u32 bad[KMC_LRX_WORDS / 2 + 2];
+    const u32 tid = threadIdx.x;
+    const u64 Q0 = q0 + (u64)blockIdx.x * KMC_LRX_POS;
+    if (Q0 >= q1) return;
+    for (u32 i = tid; i < KMC_LRX_WORDS; i += KMC_LRX_THREADS) w[i] = 0;
+    for (u32 i = tid; i < KMC_LRX_WORDS / 2 + 2; i += KMC_LRX_THREADS) bad[i] = 0;
+    __syncthreads();
+    for (u32 i = tid; i < KMC_LRX_SPAN; i += KMC_LRX_THREADS) {
+        const u64 p = Q0 + i;
+        if (p < n_bases) {
+            const int code = kmc_code_of(bases[p]);
+            if (code < 0) atomicOr(&bad[i >> 5], 0x80000000u >> (i & 31));
+            else if (code) atomicOr(&w[i >> 4], (u32)code << (30 - 2 * (i & 15)));
+        } else atomicOr(&bad[i >> 5], 0x80000000u >> (i & 31));
+    }
+    __syncthreads();
+    const u64 q = Q0 + tid;
+    if (q >= q1) return;
+    const bool ok = !(lrx_badwin(bad, tid) & 0xFFFFFFE0u);  // the first 27 of 32
+    const u64 M = lrx_window(w, tid) >> (64 - 2 * KMC_LR_L);
+    if (MODE == 0) { out_lo[q - q0] = ok ? M : ~0ull; return; }
+    u32 r = KMC_LR_NORANK;
+    if (ok) {
+        u32 lo_i = 0, hi_i = n_dict;  // last i with dict[i] <= M (M is in the dictionary)
+        while (hi_i - lo_i > 1) {
+            const u32 mid = (lo_i + hi_i) >> 1;
+            if (dict[mid] <= M) lo_i = mid; else hi_i = mid;
+        }
+        r = lo_i;
+    }
+    rank[q - q0] = r;
+}
+
+// 3. One thread per (window start, chunk size) pair, so stores are fully coalesced: key index = 61 * (p -
+//    p_begin) + (s - 80).  Pairs that do not exist (read too short for this size, window start in the last
+//    79 bases of a read) get the all-ones filler the sort drops.  rank[] is indexed from q0.
+__global__ __launch_bounds__(KMC_LRX_THREADS)
+void kmc_lr_pair_kernel(const u64* __restrict__ offsets, u64 n_reads, u64 p_begin, u64 p_end, u64 q0, u64 nq, const u32* __restrict__ rank, int B,
+                        u64* __restrict__ out_lo, u64* __restrict__ counters) {
+    __shared__ u64 rend[KMC_LRX_POS];   // end of the read a window start lies in
+    __shared__ u32 rk[KMC_LRX_POS + KMC_LRX_DMAX + 1];
     const u32 tid = threadIdx.x;
     const u64 P0 = p_begin + (u64)blockIdx.x * KMC_LRX_POS;
     if (P0 >= p_end) return;
     const u32 npos = (u32)min((u64)KMC_LRX_POS, p_end - P0);
-    for (u32 i = tid; i < KMC_LRX_WORDS; i += KMC_LRX_THREADS) w[i] = 0;
-    for (u32 i = tid; i < KMC_LRX_WORDS / 2 + 2; i += KMC_LRX_THREADS) bad[i] = 0;
-    __syncthreads();
-    // pack the span: base P0 + i
-    for (u32 i = tid; i < KMC_LRX_SPAN; i += KMC_LRX_THREADS) {
-        const u64 p = P0 + i;
-        if (p < n_bases) {
-            const uint8_t c = bases[p];
-            const int code = kmc_code_of(c);
-            if (code < 0) atomicOr(&bad[i >> 5], 0x80000000u >> (i & 31));
-            else if (code) atomicOr(&w[i >> 4], (u32)code << (30 - 2 * (i & 15)));
-        }
-    }
-    if (tid < npos) {  // the read of my window start: last r with offsets[r] <= p  (offsets[n_reads] == n_bases > p)
+    if (tid < npos) {  // the read of my window start: last r with offsets[r] <= p  (offsets[n_reads] > p)
         const u64 p = P0 + tid;
         u64 lo_i = 0, hi_i = n_reads;
         while (hi_i - lo_i > 1) {
@@ -86,30 +126,33 @@ void kmc_lr_extract_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const
         }
         rend[tid] = offsets[lo_i + 1];
     }
+    for (u32 i = tid; i < KMC_LRX_POS + KMC_LRX_DMAX + 1; i += KMC_LRX_THREADS) rk[i] = (P0 + i - q0 < nq) ? rank[P0 + i - q0] : KMC_LR_NORANK;
     __syncthreads();
     const u32 n_keys = npos * KMC_LRX_NS;
     u64 nk = 0;
     bool saw_bad = false;
     for (u32 q = tid; q < n_keys; q += KMC_LRX_THREADS) {
         const u32 t = q / KMC_LRX_NS, j = q - t * KMC_LRX_NS, sz = KMC_LR_SMIN + j;
-        u64 hi = ~0ull, lo = ~0ull;
+        u64 key = ~0ull;
         if (P0 + t + sz <= rend[t]) {  // main.rs:73-75
-            const u32 a = t, b = t + sz - KMC_LR_R;
-            const u32 mbits = 0xFFFFFFE0u;  // the first 27 of 32
-            if ((lrx_badwin(bad, a) | lrx_badwin(bad, b)) & mbits) saw_bad = true;
-            else {
-                const u64 L = lrx_window(w, a) >> (64 - 2 * KMC_LR_L);
-                const u64 R = lrx_window(w, b) >> (64 - 2 * KMC_LR_R);
-                hi = L >> (64 - 2 * KMC_LR_R);
-                lo = (L << (2 * KMC_LR_R)) | R;
-                nk++;
-            }
+            const u32 a = rk[t], b = rk[t + sz - KMC_LR_R];
+            if (a == KMC_LR_NORANK || b == KMC_LR_NORANK) saw_bad = true;
+            else { key = ((u64)a << B) | b; nk++; }
         }
-        const u64 o = (P0 - p_begin) * KMC_LRX_NS + q;
-        out_hi[o] = hi;
-        out_lo[o] = lo;
+        out_lo[(P0 - p_begin) * KMC_LRX_NS + q] = key;
     }
     if (saw_bad) atomicOr((unsigned long long*)&counters[KMC_CTR_ERR], 4ull);
     nk = wave_sum_u64(nk);
     if ((tid & 63) == 0 && nk) atomicAdd((unsigned long long*)&counters[KMC_CTR_KMERS], nk);
+}
+
+// 4. the sorted run's one-word keys back to {hi, lo} = L (54 bits) ++ R (54 bits)
+__global__ void kmc_lr_compose_kernel(u64* __restrict__ r_hi, u64* __restrict__ r_lo, u64 n, const u64* __restrict__ dict, int B) {
+    const u64 mask = (1ull << B) - 1ull;
+    for (u64 i = blockIdx.x * (u64)blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 key = r_lo[i];
+        const u64 L = dict[key >> B], R = dict[key & mask];
+        r_hi[i] = L >> (64 - 2 * KMC_LR_R);
+        r_lo[i] = (L << (2 * KMC_LR_R)) | R;
+    }
 }
