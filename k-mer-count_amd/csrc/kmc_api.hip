@@ -74,7 +74,7 @@ struct kmc_ctx {
     DevBuf vr_reads, vr_cnt, vr_pos;  // pieces of long reads for the walk kernel: [starts | ends], per-read counts and their scan
     DevBuf walk_memo;  // two shared memo snapshots + dense counters, kept across launches (kmc_walk.hip.h)
     int memo_parity = 0;  // snapshot slot the next walk launch reads
-    bool walk_ws_clean = false;  // workspace header + dense counters are zero (left so by kmc_walk_unfold_kernel)
+    bool walk_ws_clean = false;  // workspace header + dense counters are zero (left so by kmc_walk_tail_kernel)
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
     DevBuf s_lo[2], s_hi[2];
     DevBuf lr_rank;  // LR mode: rank of every position's 27-mer among the batch's distinct 27-mers
@@ -93,6 +93,7 @@ struct kmc_ctx {
     size_t lev_used = 0;
     kmc_stats st{};
     int fin_parity = 0;    // which OUT/SUM counter pair the next kmc_finalize uses
+    u64 fin_hint = 0;      // table entries at the last kmc_finalize (sizes the next speculative small-table finalize)
     bool timed = false;    // ev0/ev1 bracket a finished batch
     bool batch_pending = false;  // a COUNT kernel (unknown number of new keys) is queued since the last poll
     u64 unpolled_adds = 0;       // upper bound of keys added by merge kernels since the last poll
@@ -111,6 +112,7 @@ struct kmc_ctx {
     struct Risky {
         bool armed = false;
         int mode = 0;                 // 1: entries listed in occ_list; 2: whole table copied
+        bool empty = false;           // mode 1 and the table held nothing: there is nothing to save (no kernel)
         const uint8_t* d_bases = nullptr; const u64* d_offsets = nullptr; u64 n_reads = 0, n_bases = 0;
         u64 base_from = 0;            // first base position the risky launch covers ...
         const u64* d_from = nullptr;  // ... or where to read it on the device (end of the last piece walked before)
@@ -293,8 +295,8 @@ int sk_ensure(kmc_ctx* c) {
     HIPCHK(c, hipMalloc((void**)&c->sk.lo, cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk.cnt, cap * sizeof(u64)));
     if (three) HIPCHK(c, hipMalloc((void**)&c->sk.mid, cap * sizeof(u64)));
-    HIPCHK(c, hipMalloc((void**)&c->d_sk_counters, KMC_CTR_N * sizeof(u64)));
-    HIPCHK(c, hipHostMalloc((void**)&c->h_sk_counters, KMC_CTR_N * sizeof(u64)));
+    c->d_sk_counters = c->d_counters + KMC_CTR_N;
+    c->h_sk_counters = c->h_counters + KMC_CTR_N;
     c->sk_spill_cap = std::max<u64>(cap / 64, 4096);
     HIPCHK(c, hipMalloc((void**)&c->sk_spill_hi, c->sk_spill_cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk_spill_lo, c->sk_spill_cap * sizeof(u64)));
@@ -323,8 +325,7 @@ auto kw_dispatch(int KW, F1 f1, F2 f2) { return KW == 1 ? f1() : f2(); }
 
 // read the device counters (synchronises the stream)
 int poll(kmc_ctx* c) {
-    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, KMC_CTR_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    if (c->sk.lo) HIPCHK(c, hipMemcpyAsync(c->h_sk_counters, c->d_sk_counters, KMC_CTR_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, (c->sk.lo ? 2 : 1) * KMC_CTR_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->pending = false;
     c->batch_pending = false;
@@ -424,6 +425,36 @@ int poll_and_settle(kmc_ctx* c) {
     int rc = poll(c);
     if (rc) return rc;
     return settle(c);
+}
+
+// Give the counts of the (k+16)-mer table to their k-mers (kmc_sk_unfold_kernel).  What the last poll
+// saw of that table is certain to come (16 k-mers per entry): room is made for it first.  Entries
+// added since then are covered like any prediction: by the table saved in front of the launch
+// that added them.  (Growing re-inserts the table, which a saved COPY of the table would not
+// survive; a saved entry list does.)
+// The unfold is DEFERRED: a batch's walk launches leave sk_dirty set, and whoever looks at the count
+// table next settles it -- the next batch (two tiny launches, no synchronisation), kmc_finalize (which
+// polls anyway and launches nothing when the poll shows the (k+16)-mer table empty: the benchmark's
+// steady state, where the unconditional unfold + spill reset cost 9 us of a 280 us step), pack / reset.
+int flush_sk(kmc_ctx* c) {
+    const u64 sk_known = c->h_sk_counters ? c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] : 0;
+    const u64 occ0 = c->h_counters[KMC_CTR_OCCUPIED];
+    if (sk_known && (occ0 + 16 * sk_known) * 10 > c->tab.cap * 7 && !(c->risky.armed && c->risky.mode == 2)) {
+        int r = grow_to(c, next_pow2((occ0 + 16 * sk_known) * 2));
+        if (r) return r;
+    }
+    int r = kmc_sk_unfold_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, sk_table_of(c), gtable_of(c, c->tab));
+    if (r) return fail(c, r, "(k+16)-mer unfold launch failed");
+    c->sk_dirty = false;
+    c->pending = true;
+    return KMC_OK;
+}
+
+// right after a poll: launch nothing when the poll shows the (k+16)-mer table empty
+int settle_sk_polled(kmc_ctx* c) {
+    if (!c->sk_dirty) return KMC_OK;
+    if (!c->h_sk_counters || c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] == 0) { c->sk_dirty = false; return KMC_OK; }
+    return flush_sk(c);
 }
 
 // ---- launching the counting kernels ---------------------------------------------------------
@@ -661,7 +692,12 @@ bool arm_risky(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_r
     const u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
     kmc_ctx::Risky& r = c->risky;
     GTable g = gtable_of(c, c->tab);
-    if (occ <= KMC_OCC_LIST_CAP && c->occ_list && c->h_counters[KMC_CTR_SPILL] == 0) {
+    r.empty = false;
+    if (occ == 0 && c->h_counters[KMC_CTR_SPILL] == 0 && !c->pending) {
+        // a table that is known to be empty (the usual case: reset, then one batch) needs no snapshot at all
+        r.mode = 1;
+        r.empty = true;
+    } else if (occ <= KMC_OCC_LIST_CAP && c->occ_list && c->h_counters[KMC_CTR_SPILL] == 0) {
         const size_t nb = (size_t)KMC_OCC_LIST_CAP * sizeof(u64);
         if (ensure(c, c->snap_lo, nb) || ensure(c, c->snap_cnt, nb) || ensure(c, c->snap_n, 64) || (c->KW == 2 && ensure(c, c->snap_hi, nb))) return false;
         if (c->KW == 1) hipLaunchKernelGGL(kmc_snapshot_kernel<1>, dim3(32), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->snap_lo.p, (u64*)c->snap_cnt.p, (u64*)c->snap_n.p);
@@ -701,8 +737,10 @@ int recover_overflow(kmc_ctx* c) {
     ctr[KMC_CTR_FASTFIN] = 0;  // (a speculative finalize queued in front of this poll looked at the overflowed table)
     if (r.mode == 1) {
         u64 n_snap = 0;
-        HIPCHK(c, hipMemcpyAsync(&n_snap, c->snap_n.p, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (!r.empty) {
+            HIPCHK(c, hipMemcpyAsync(&n_snap, c->snap_n.p, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+        }
         if (n_snap == ~0ull) return fail(c, KMC_ERR_CAPACITY, "count table and spill area exhausted and the table could not be restored; raise capacity_hint");
         const int grid = grid_for(c, c->tab.cap, 256);
         if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g);
@@ -775,7 +813,15 @@ int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
 }
 
 int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len) {
-    if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
+    if (c->pending) {
+        int rc = poll_and_settle(c);
+        if (rc) return rc;
+        rc = settle_sk_polled(c);  // (the previous batch's (k+16)-mer counts, if it left any)
+        if (rc) return rc;
+    } else if (c->sk_dirty) {
+        int rc = flush_sk(c);
+        if (rc) return rc;
+    }
     c->recovered = false;
     c->sorted_valid = false;
     c->st.n_reads += n_reads;
@@ -858,24 +904,6 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
             observed_kmers += (double)units * (double)kmers_per_unit;
             u64 occ_all = occ_after + c->h_counters[KMC_CTR_SPILL];
             c->rho_hist = (double)(occ_all > c->b_occ0 ? occ_all - c->b_occ0 : 0) / std::max(observed_kmers, 1.0);
-            return KMC_OK;
-        };
-        // Give the counts of the (k+16)-mer table to their k-mers (kmc_sk_unfold_kernel).  What the last poll
-        // saw of that table is certain to come (16 k-mers per entry): room is made for it first.  Entries
-        // added since then are covered like any prediction: by the table saved in front of the launch
-        // that added them.  (Growing re-inserts the table, which a saved COPY of the table would not
-        // survive; a saved entry list does.)
-        auto flush_sk = [&]() -> int {
-            const u64 sk_known = c->h_sk_counters ? c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] : 0;
-            const u64 occ0 = c->h_counters[KMC_CTR_OCCUPIED];
-            if (sk_known && (occ0 + 16 * sk_known) * 10 > c->tab.cap * 7 && !(c->risky.armed && c->risky.mode == 2)) {
-                int r = grow_to(c, next_pow2((occ0 + 16 * sk_known) * 2));
-                if (r) return r;
-            }
-            int r = kmc_sk_unfold_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, sk_table_of(c), gtable_of(c, c->tab));
-            if (r) return fail(c, r, "(k+16)-mer unfold launch failed");
-            c->sk_dirty = false;
-            c->pending = true;
             return KMC_OK;
         };
         const bool lr = c->cfg.mode == KMC_MODE_LR;
@@ -981,7 +1009,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                     // the launches before it must be IN that table first (a recovery drops the (k+16)-mer
                     // table's counts together with the failed launch's).  This is a poll point: the unfold is
                     // sized exactly, and one more poll tells the planner what the table looks like now.
-                    rc = flush_sk();
+                    rc = flush_sk(c);
                     if (rc) return rc;
                     rc = poll_and_settle(c);
                     if (rc) return rc;
@@ -996,7 +1024,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 if (skt.key_lo && !c->risky.armed) {
                     const u64 max_adds = take * 64ull * (KMC_WALK_MAX_READ / KMC_WALK_STRIDE + 1);
                     if ((c->h_sk_counters[KMC_CTR_OCCUPIED] + max_adds) * 4 > c->sk.cap * 3 && c->sk_dirty) {
-                        rc = flush_sk();   // (as above: nothing of earlier launches may be lost with this one)
+                        rc = flush_sk(c);   // (as above: nothing of earlier launches may be lost with this one)
                         if (rc) return rc;
                         rc = poll_and_settle(c);
                         if (rc) return rc;
@@ -1049,10 +1077,6 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                     }
                 }
             }
-        }
-        if (c->sk_dirty && !c->recovered) {   // the batch's walk launches are through
-            rc = flush_sk();
-            if (rc) return rc;
         }
         if (c->recovered) { run_stream = false; run_sort = false; c->sk_dirty = false; }
         if (run_stream) {
@@ -1157,8 +1181,6 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
                       &c->snap_hi, &c->snap_lo, &c->snap_cnt, &c->snap_n, &c->snap_occ, &c->rx_hi, &c->rx_lo, &c->rx_cnt};
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     free_table(c->sk);
-    if (c->d_sk_counters) (void)hipFree(c->d_sk_counters);
-    if (c->h_sk_counters) (void)hipHostFree(c->h_sk_counters);
     if (c->sk_spill_hi) (void)hipFree(c->sk_spill_hi);
     if (c->sk_spill_lo) (void)hipFree(c->sk_spill_lo);
     if (c->sk_spill_cnt) (void)hipFree(c->sk_spill_cnt);
@@ -1199,10 +1221,10 @@ static int kmc_create_impl(kmc_ctx** out, const kmc_config* cfg) {
         else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
         HIPCHK(c, hipEventCreate(&c->ev0));
         HIPCHK(c, hipEventCreate(&c->ev1));
-        HIPCHK(c, hipMalloc((void**)&c->d_counters, KMC_CTR_N * sizeof(u64)));
-        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, KMC_CTR_N * sizeof(u64), c->stream));
-        HIPCHK(c, hipHostMalloc((void**)&c->h_counters, KMC_CTR_N * sizeof(u64)));
-        memset(c->h_counters, 0, KMC_CTR_N * sizeof(u64));
+        HIPCHK(c, hipMalloc((void**)&c->d_counters, 2 * KMC_CTR_N * sizeof(u64)));  // [count table | (k+16)-mer table]: one read-back
+        HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 2 * KMC_CTR_N * sizeof(u64), c->stream));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_counters, 2 * KMC_CTR_N * sizeof(u64)));
+        memset(c->h_counters, 0, 2 * KMC_CTR_N * sizeof(u64));
         u64 cap = next_pow2(std::max<u64>(cfg->capacity_hint * 2, 1ull << 20));
         c->spill_cap = std::max<u64>(cap / 4, 1ull << 18);
         HIPCHK(c, hipMalloc((void**)&c->occ_list, KMC_OCC_LIST_CAP * sizeof(u64)));
@@ -1230,6 +1252,7 @@ static int kmc_create_impl(kmc_ctx** out, const kmc_config* cfg) {
 static int kmc_reset_impl(kmc_ctx* c) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->sk_dirty) { int r = flush_sk(c); if (r) return r; }  // (empties the (k+16)-mer table; its counts go with the table)
     {
         GTable g = gtable_of(c, c->tab);
         int grid = grid_for(c, c->tab.cap, 256);
@@ -1320,6 +1343,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc;
     bool tried_fast = false;
+    int fgrid_used = 0;
     if (c->runs.empty()) {
         // speculative small-table finalize, queued behind whatever is still running
         const size_t fb = (size_t)KMC_OCC_LIST_CAP * sizeof(u64);
@@ -1327,14 +1351,46 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         rc = ensure(c, c->o_cnt, fb); if (rc) return rc;
         if (c->KW == 2) { rc = ensure(c, c->o_hi, fb); if (rc) return rc; }
         GTable g = gtable_of(c, c->tab);
-        const int fgrid = KMC_OCC_LIST_CAP / KMC_FIN_CHUNK;  // workgroups beyond ceil(n / 64) leave at once
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(fgrid), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
-        else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(fgrid), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+        // one workgroup per 64 keys; the grid follows the size of the last table seen (x2), at least 128
+        // workgroups: 512 workgroups of which 460 leave at once cost 3 us more than 128 on the benchmark's
+        // 3,350 keys.  A table that outgrew the grid is noticed below and finalized again with the full grid.
+        fgrid_used = (int)std::min<u64>(KMC_OCC_LIST_CAP / KMC_FIN_CHUNK, std::max<u64>(128, next_pow2(2 * c->fin_hint / KMC_FIN_CHUNK + 1)));
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+        else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
         HIPCHK(c, hipGetLastError());
         tried_fast = true;
     }
     rc = poll_and_settle(c);
     if (rc) return rc;
+    if (c->sk_dirty) {
+        // the last batch's walk launches may have left counts in the (k+16)-mer table: the poll tells
+        const bool had = c->h_sk_counters && c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] != 0;
+        rc = settle_sk_polled(c);
+        if (rc) return rc;
+        if (had) {  // the table changed under the speculative finalize: once more
+            if (tried_fast && c->runs.empty()) {
+                GTable g = gtable_of(c, c->tab);
+                fgrid_used = KMC_OCC_LIST_CAP / KMC_FIN_CHUNK;
+                if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+                else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+                HIPCHK(c, hipGetLastError());
+            }
+            rc = poll_and_settle(c);
+            if (rc) return rc;
+        }
+    }
+    c->fin_hint = c->h_counters[KMC_CTR_OCCUPIED];
+    if (tried_fast && c->runs.empty() && c->h_counters[KMC_CTR_FASTFIN] != 1 && c->h_counters[KMC_CTR_SPILL] == 0 &&
+        c->h_counters[KMC_CTR_OCCUPIED] > (u64)fgrid_used * KMC_FIN_CHUNK && c->h_counters[KMC_CTR_OCCUPIED] <= KMC_OCC_LIST_CAP) {
+        // the table outgrew the speculative grid (first finalize of a larger source): once more, full grid
+        GTable g = gtable_of(c, c->tab);
+        fgrid_used = KMC_OCC_LIST_CAP / KMC_FIN_CHUNK;
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+        else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+        HIPCHK(c, hipGetLastError());
+        rc = poll_and_settle(c);
+        if (rc) return rc;
+    }
     const bool fast_done = tried_fast && c->h_counters[KMC_CTR_FASTFIN] == 1 && c->runs.empty();  // (the poll may have recovered an overflow: runs exist now)
     const u64 n_tab = c->h_counters[KMC_CTR_OCCUPIED];
     u64 n_runs_total = 0;
@@ -1490,6 +1546,7 @@ static int kmc_pack_slab_device_impl(kmc_ctx* c, void* d_slab, uint64_t slab_ent
     if (!c || !d_slab || !slab_entries) return c ? fail(c, KMC_ERR_ARG, "kmc_pack_slab_device: null slab or zero capacity") : KMC_ERR_ARG;
     if (((uintptr_t)d_slab & 7) != 0) return fail(c, KMC_ERR_ARG, "d_slab must be 8-byte aligned");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->sk_dirty) { int r = flush_sk(c); if (r) return r; }
     if (!c->sorted_valid) {
         // not finalized: pack the live table (unsorted) -- the device decides whether it fits
         GTable g = gtable_of(c, c->tab);

@@ -256,7 +256,8 @@ void kmc_small_finalize_kernel(GTable g, u32* __restrict__ rank, u64* __restrict
     __shared__ u64 s_sum[16];
     const u32 tid = threadIdx.x;
     const u64 n = g.counters[KMC_CTR_OCCUPIED];
-    const bool ok = n > 0 && n <= KMC_OCC_LIST_CAP && n <= g.occ_list_cap && g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0;
+    const bool ok = n > 0 && n <= KMC_OCC_LIST_CAP && n <= g.occ_list_cap && n <= (u64)gridDim.x * KMC_FIN_CHUNK &&
+                    g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0;
     if (!ok) {  // (every workgroup reads the same counters; nothing else writes them while this kernel runs)
         if (blockIdx.x == 0 && tid == 0) { g.counters[KMC_CTR_FASTFIN] = 0; g.counters[KMC_CTR_SUM2] = 0; }
         return;

@@ -30,7 +30,7 @@
 // counter in LDS (the SIMD arbiter favours older waves; with fixed shares half of them idled for
 // the last third of the kernel).  Reads longer than KMC_WALK_MAX_READ are walked as pieces that
 // overlap by k-1 bases (kmc_vreads_*).  Reads that contain a non-ACGT byte are diverted to a scalar
-// kernel (kmc_scalar_reads_kernel).  Measured: 1.33 ms for 8.95 G bases = 6.8 TB/s, 85 % of the HBM
+// kernel (the scalar part of kmc_walk_tail_kernel).  Measured: 1.33 ms for 8.95 G bases = 6.8 TB/s, 85 % of the HBM
 // peak.
 #pragma once
 #include "../../include/kmc.h"
@@ -86,10 +86,12 @@ struct WalkLds {
 
 // workspace (device): [WalkWs header | gcnt[NCAP+ECAP] dense snapshot counters | u32 deferred read
 // indices]; header and counters are zero before every launch: cleared once by the host when the
-// buffer is (re)allocated, afterwards by kmc_walk_unfold_kernel, their last reader
+// buffer is (re)allocated, afterwards by kmc_walk_tail_kernel, their last reader
 struct WalkWs {
     unsigned long long n_deferred;
-    unsigned long long pad[7];
+    unsigned int scalar_done;   // workgroups of the scalar part that have read n_deferred (kmc_walk_tail_kernel)
+    unsigned int pad0;
+    unsigned long long pad[6];
 };
 #define KMC_WALK_WS_PREFIX (sizeof(WalkWs) + (size_t)(KMC_WALK_NCAP + KMC_WALK_ECAP) * sizeof(u64))
 
@@ -98,7 +100,7 @@ struct WalkWs {
 // and EVERY workgroup of the next launch starts from that snapshot.  That removes the warm-up of the
 // slow path, and -- because all workgroups then agree on the slot of every snapshot entry -- lets
 // them reduce their per-slot traversal counters with dense, coalesced atomics into one small global
-// array (gcnt) that kmc_walk_unfold_kernel turns into k-mer counts ONCE, instead of every
+// array (gcnt) that kmc_walk_tail_kernel turns into k-mer counts ONCE, instead of every
 // workgroup scattering ~4 k global adds for the same k-mers (the flush was 70 us of a 1.7 ms launch).
 // Entries a workgroup discovers during the launch are not in the snapshot and take the scattered
 // path.  Two snapshot slots alternate (read A / write B) so that nothing reads a slot being written.
@@ -262,7 +264,14 @@ __device__ __forceinline__ u32 walk_node(WalkLds<KW>& L, WCtx nk) {
 // the (k+16)-mer of a step: context (2k bits, public code, newest base lowest) followed by the label
 // (16 bases, internal code, first base in the low bits)
 // count one traversal of the step (ctx, label) in the (k+16)-mer table
+#ifdef KMC_SK_ADD_NOINLINE
+__device__ __noinline__ void sk_add(const GTable& sk, WCtx ctx, u32 label) {
+#else
 __device__ __forceinline__ void sk_add(const GTable& sk, WCtx ctx, u32 label) {
+#endif
+#ifdef KMC_WALK_NO_SK
+    return;
+#endif
     const u32 pub = label ^ ((label >> 1) & 0x55555555u);  // A0 C1 T2 G3 -> A0 C1 G2 T3
     const u32 be = le_to_be(pub);                           // first base of the step in the top bits
     const u64 lo = (ctx.lo << 32) | be;
@@ -453,7 +462,11 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     extern __shared__ __align__(16) unsigned char walk_smem[];
     WalkLds<KW>& L = *reinterpret_cast<WalkLds<KW>*>(walk_smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#ifdef KMC_WALK_ONE_COUNTER
+    const u32 cpar = 0u;
+#else
     const u32 cpar = (u32)lane & 1u;  // which of the two traversal counters of a node / edge this lane uses
+#endif
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
@@ -791,13 +804,9 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
 // Turns the traversal counters that all workgroups reduced into gcnt (one per snapshot slot) into
 // k-mer counts, once per launch (gcnt is cleared by kmc_walk_prepare before the next launch).
 template <int KW, bool CANON>
-__global__ __launch_bounds__(256)
-void kmc_walk_unfold_kernel(const WalkMemoSlot<KW>* memo, u64* gcnt, WalkWs* ws, int k, GTable g) {
-    // the scalar kernel (queued before this one) was the last reader of the deferred-read counter:
-    // leave the workspace clean for the next launch (no memset per launch)
-    if (blockIdx.x == 0 && threadIdx.x == 0) ws->n_deferred = 0;
+__device__ __forceinline__ void walk_unfold_part(const WalkMemoSlot<KW>* memo, u64* gcnt, int k, const GTable& g, u32 block, u32 n_blocks) {
     if (memo->tag != (KMC_WALK_MEMO_TAG | (u64)k)) return;  // the launch ran without a snapshot: gcnt untouched
-    const u32 tid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    const u32 tid = block * blockDim.x + threadIdx.x, nthreads = n_blocks * blockDim.x;
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
@@ -825,20 +834,30 @@ void kmc_walk_unfold_kernel(const WalkMemoSlot<KW>* memo, u64* gcnt, WalkWs* ws,
     // every entry is read by 16 consecutive threads of ONE block (the grid covers the item space exactly
     // once): after the block's reads, clear its entries for the next launch
     __syncthreads();
-    if (threadIdx.x < 256 / KMC_WALK_STRIDE) gcnt[blockIdx.x * (256 / KMC_WALK_STRIDE) + threadIdx.x] = 0;
+    if (threadIdx.x < 256 / KMC_WALK_STRIDE) gcnt[block * (256 / KMC_WALK_STRIDE) + threadIdx.x] = 0;
 }
 
 // One lane per listed read, byte by byte: reads diverted from the walk kernel (non-ACGT bytes).
 template <int KW, bool CANON>
-__global__ void kmc_scalar_reads_kernel(const uint8_t* __restrict__ bases, const u64* __restrict__ vstart, const u64* __restrict__ vend,
-                                        WalkWs* ws, const u32* __restrict__ list, int k, GTable g) {
-    const u64 n = ws->n_deferred;
-    if (n == 0) return;  // (the common case; the header is cleared by the host only after a non-empty run)
+__device__ __forceinline__ void walk_scalar_part(const uint8_t* __restrict__ bases, const u64* __restrict__ vstart, const u64* __restrict__ vend,
+                                                 WalkWs* ws, const u32* __restrict__ list, int k, const GTable& g, u32 block, u32 n_blocks) {
+    // every workgroup of this part reads the deferred-read counter; the last one to have read it leaves the
+    // workspace clean for the next launch (no memset per launch)
+    __shared__ u64 s_n;
+    if (threadIdx.x == 0) {
+        s_n = __hip_atomic_load(&ws->n_deferred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence();  // (the read above before the ticket below)
+        const u32 t = atomicAdd(&ws->scalar_done, 1u);
+        if (t == n_blocks - 1) { ws->n_deferred = 0; ws->scalar_done = 0; }
+    }
+    __syncthreads();
+    const u64 n = s_n;
+    if (n == 0) return;  // (the common case)
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
     u64 nk = 0;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+    for (u64 i = (u64)block * blockDim.x + threadIdx.x; i < n; i += (u64)n_blocks * blockDim.x) {
         const u64 r = list[i];
         u64 lo = 0, hi = 0;
         int run = 0;
@@ -862,6 +881,18 @@ __global__ void kmc_scalar_reads_kernel(const uint8_t* __restrict__ bases, const
     }
     nk = wave_sum_u64(nk);
     if ((threadIdx.x & 63) == 0 && nk) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_KMERS], nk);
+}
+
+// What follows a walk launch, in ONE launch (two launches cost 4 us more per step): the first n_unfold
+// workgroups turn the dense traversal counters into k-mer counts, the others count the diverted reads.
+// The two parts touch disjoint state (gcnt / the deferred list) and both only add to the count table.
+#define KMC_WALK_UNFOLD_BLOCKS ((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE / 256)
+template <int KW, bool CANON>
+__global__ __launch_bounds__(256)
+void kmc_walk_tail_kernel(const uint8_t* __restrict__ bases, const u64* __restrict__ vstart, const u64* __restrict__ vend,
+                          WalkWs* ws, const u32* __restrict__ list, const WalkMemoSlot<KW>* memo, u64* gcnt, int k, GTable g) {
+    if (blockIdx.x < KMC_WALK_UNFOLD_BLOCKS) walk_unfold_part<KW, CANON>(memo, gcnt, k, g, blockIdx.x, KMC_WALK_UNFOLD_BLOCKS);
+    else walk_scalar_part<KW, CANON>(bases, vstart, vend, ws, list, k, g, blockIdx.x - KMC_WALK_UNFOLD_BLOCKS, gridDim.x - KMC_WALK_UNFOLD_BLOCKS);
 }
 
 // ---- host side ------------------------------------------------------------------------------
@@ -919,10 +950,9 @@ static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const u
         hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_vstart, d_vend, n_reads, k, tile_begin, tile_end, hdr, list,
                            (const WalkMemoSlot<KW>*)&slots[parity], &slots[parity ^ 1], gcnt, g, sk);
     } else {
-        hipLaunchKernelGGL((kmc_scalar_reads_kernel<KW, CANON>), dim3(n_cu), dim3(256), 0, st, d_bases, d_vstart, d_vend, hdr, list, k, g);
         static_assert(((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE) % 256 == 0 && 256 % KMC_WALK_STRIDE == 0, "unfold grid must cover the items exactly");
-        hipLaunchKernelGGL((kmc_walk_unfold_kernel<KW, CANON>), dim3((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE / 256), dim3(256), 0, st,
-                           (const WalkMemoSlot<KW>*)&slots[parity], gcnt, hdr, k, g);
+        hipLaunchKernelGGL((kmc_walk_tail_kernel<KW, CANON>), dim3(KMC_WALK_UNFOLD_BLOCKS + n_cu), dim3(256), 0, st,
+                           d_bases, d_vstart, d_vend, hdr, list, (const WalkMemoSlot<KW>*)&slots[parity], gcnt, k, g);
     }
 }
 
