@@ -216,6 +216,16 @@ def main():
                 "launches_per_step": int(round(float(np.mean(launches)))) if launches else None,
                 "kernel_ms_cold_memo": round(float(np.mean(cold_ms)), 4) if cold_ms else None,
                 "algorithmic_bytes_per_step": algo_bytes}
+    if algo_used == "sort":
+        # The sort path's own traffic: one key per base position out of the extraction, two
+        # levels of histogram read + scatter read/write, the leaves (read, staged keys + counts written), the
+        # gather (both read, both written): n_bases + 13 n_kmers key-units of 8 B (k <= 31) or 16 B.  `frac`
+        # above prices the INPUT bytes (the metric's definition); this prices the pipeline against HBM.
+        kb = 8 if k <= 31 else 16
+        model = (n_bases + 13 * n_kmers) * kb
+        roofline["sort_pipeline"] = {"model_bytes_per_step": model, "achieved": round(model / (k_ms * 1e-3) / 1e9, 1), "unit": "GB/s",
+                                     "frac": round(model / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "kernels": "kmc_stream_kernel<SINK=1>, kmc_msd_{hist,scan_a,scan,scatter,leaf,gather}_kernel"}
 
     # ---- CPU baseline: the oracle (port of the reference's algorithm), bounded sample ----------
     cpu = None

@@ -128,6 +128,8 @@ struct kmc_ctx {
     u64* sk_occ = nullptr;          // list of its claimed slots (what the unfold kernel walks)
     bool recovered = false;  // the last poll found an overflow and recovered: the batch in flight is complete
     bool sk_dirty = false;   // walk launches since the last unfold of the (k+16)-mer table
+    bool sk_fixed = false;   // its size was set by KMC_SK_SLOTS (tests): never re-allocated
+    bool sk_grow = false;    // a poll found it more than half full: re-allocate larger when it is next empty
     DevBuf rx_hi, rx_lo, rx_cnt;  // receive buffers of the one-process multi-GPU reduce (a peer's sorted table)
 };
 
@@ -284,12 +286,18 @@ int sk_clear(kmc_ctx* c) {
     return KMC_OK;
 }
 
-// the walk kernel's (k+16)-mer table: allocated at the first walk launch of a ctx with k <= 47
-int sk_ensure(kmc_ctx* c) {
-    if (c->sk.lo || c->cfg.mode != KMC_MODE_CONTIG) return KMC_OK;
+// the walk kernel's (k+16)-mer table: allocated at the first walk launch of a ctx.  It starts at 1 Mi slots
+// (a fresh ctx's first file -> table run paid 15 ms for allocating and clearing 16 Mi slots it never used)
+// and is re-allocated sixteen times larger, once, when a poll finds it more than half full -- at a moment
+// when it is empty (right behind its unfold), so nothing has to be re-inserted.
+void sk_free(kmc_ctx* c) {
+    free_table(c->sk);
+    c->sk = Table{};
+    u64** p[] = {&c->sk_spill_hi, &c->sk_spill_lo, &c->sk_spill_cnt, &c->sk_spill_mid, &c->sk_occ};
+    for (u64** q : p) { if (*q) (void)hipFree(*q); *q = nullptr; }
+}
+int sk_alloc(kmc_ctx* c, u64 cap) {
     const bool three = c->cfg.k > KMC_SK_MAX_K;  // a (k+16)-mer of more than 63 bases: three key words
-    u64 cap = 1ull << 24;
-    if (const char* e = getenv("KMC_SK_SLOTS")) { u64 v = strtoull(e, nullptr, 10); if (v >= 1024) { cap = 1; while (cap < v) cap <<= 1; } }
     c->sk.cap = cap;
     HIPCHK(c, hipMalloc((void**)&c->sk.hi, cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk.lo, cap * sizeof(u64)));
@@ -304,6 +312,22 @@ int sk_ensure(kmc_ctx* c) {
     if (three) HIPCHK(c, hipMalloc((void**)&c->sk_spill_mid, c->sk_spill_cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk_occ, cap * sizeof(u64)));
     return sk_clear(c);
+}
+int sk_ensure(kmc_ctx* c) {
+    if (c->sk.lo || c->cfg.mode != KMC_MODE_CONTIG) return KMC_OK;
+    u64 cap = 1ull << 20;
+    if (const char* e = getenv("KMC_SK_SLOTS")) { u64 v = strtoull(e, nullptr, 10); if (v >= 1024) { cap = 1; while (cap < v) cap <<= 1; c->sk_fixed = true; } }
+    return sk_alloc(c, cap);
+}
+// the (k+16)-mer table is empty (stream order: right behind its unfold) and was found too small: once, x16
+int sk_regrow(kmc_ctx* c) {
+    if (!c->sk_grow || !c->sk.lo) return KMC_OK;
+    c->sk_grow = false;
+    const u64 cap = std::min<u64>(c->sk.cap * 16, 1ull << 24);
+    if (cap <= c->sk.cap) return KMC_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    sk_free(c);
+    return sk_alloc(c, cap);
 }
 
 u64 next_pow2(u64 v) {
@@ -338,7 +362,10 @@ int poll(kmc_ctx* c) {
         u64 dd = d - c->direct_seen, dn = n - c->kmers_seen;
         if (d >= c->direct_seen && n > c->kmers_seen && (c->st.algo_last == KMC_ALGO_WALK || c->st.algo_last == KMC_ALGO_STREAM)) c->walk_overflowed = dd * 20 > dn;
         // the second-level memo more than half full: this input has too many distinct (k+16)-mers for it
-        if (c->sk.lo && (c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL]) * 2 > c->sk.cap) c->walk_overflowed = true;
+        if (c->sk.lo && (c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL]) * 2 > c->sk.cap) {
+            if (!c->sk_fixed && c->sk.cap < (1ull << 24)) c->sk_grow = true;  // (first: a larger one)
+            else c->walk_overflowed = true;
+        }
         c->direct_seen = d;
         c->kmers_seen = n;
     }
@@ -447,13 +474,13 @@ int flush_sk(kmc_ctx* c) {
     if (r) return fail(c, r, "(k+16)-mer unfold launch failed");
     c->sk_dirty = false;
     c->pending = true;
-    return KMC_OK;
+    return sk_regrow(c);
 }
 
 // right after a poll: launch nothing when the poll shows the (k+16)-mer table empty
 int settle_sk_polled(kmc_ctx* c) {
     if (!c->sk_dirty) return KMC_OK;
-    if (!c->h_sk_counters || c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] == 0) { c->sk_dirty = false; return KMC_OK; }
+    if (!c->h_sk_counters || c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] == 0) { c->sk_dirty = false; return sk_regrow(c); }
     return flush_sk(c);
 }
 
@@ -1029,6 +1056,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                         rc = poll_and_settle(c);
                         if (rc) return rc;
                         if (c->recovered) break;
+                        skt = sk_table_of(c);  // (the flush may have re-allocated it larger)
                     }
                     if ((c->h_sk_counters[KMC_CTR_OCCUPIED] + max_adds) * 4 > c->sk.cap * 3 &&
                         !arm_risky(c, d_bases, d_offsets, n_reads, n_bases, 0, done ? d_ve + (done * 64 - 1) : nullptr))
@@ -1180,12 +1208,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
                       &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_cnt, &c->m_w[0], &c->m_w[1],
                       &c->snap_hi, &c->snap_lo, &c->snap_cnt, &c->snap_n, &c->snap_occ, &c->rx_hi, &c->rx_lo, &c->rx_cnt};
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
-    free_table(c->sk);
-    if (c->sk_spill_hi) (void)hipFree(c->sk_spill_hi);
-    if (c->sk_spill_lo) (void)hipFree(c->sk_spill_lo);
-    if (c->sk_spill_cnt) (void)hipFree(c->sk_spill_cnt);
-    if (c->sk_spill_mid) (void)hipFree(c->sk_spill_mid);
-    if (c->sk_occ) (void)hipFree(c->sk_occ);
+    sk_free(c);
     try { free_runs(c, true); } catch (...) { /* (only the pool bookkeeping can throw; the buffers it could not list leak with the process) */ }
     for (DevBuf* b : bufs) free_buf(*b);
     for (hipEvent_t e : c->lev) (void)hipEventDestroy(e);

@@ -1,5 +1,5 @@
 """The bench.py output contract, checked on the committed line of the last GPU run
-(profiles/r01_bench_n1.json): the keys and types the driver and the judge read."""
+(profiles/r02_bench_n1.json; the strong-scaling rehearsal line next to it): the keys and types the driver and the judge read."""
 import json
 import os
 
@@ -7,7 +7,7 @@ from conftest import ROOT
 
 
 def test_committed_bench_line_has_the_contract_keys():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_bench_n1.json")))
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")))
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict),
                      ("roofline", dict), ("cpu_baseline", dict)):
@@ -23,3 +23,11 @@ def test_committed_bench_line_has_the_contract_keys():
     assert abs(line["value"] - kmers / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
     cb = line["cpu_baseline"]
     assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb and cb["gpu_bit_exact_on_sample"] is True
+    assert line["config"]["exact_full_size_check"]["bit_exact"] is True   # the full-size table against the analytic oracle
+
+
+def test_strong_scaling_line_says_so():
+    line = json.load(open(os.path.join(ROOT, "profiles", "r02_rehearsal_n2_strong_one_gpu_gloo.json")))
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    weak = json.load(open(os.path.join(ROOT, "profiles", "r02_rehearsal_n2_one_gpu_gloo.json")))
+    assert weak["scaling"] == "weak" and weak["n_gpus"] == 2
