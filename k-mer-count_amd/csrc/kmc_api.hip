@@ -840,15 +840,10 @@ int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
 }
 
 int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len) {
-    if (c->pending) {
-        int rc = poll_and_settle(c);
-        if (rc) return rc;
-        rc = settle_sk_polled(c);  // (the previous batch's (k+16)-mer counts, if it left any)
-        if (rc) return rc;
-    } else if (c->sk_dirty) {
-        int rc = flush_sk(c);
-        if (rc) return rc;
-    }
+    if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
+    // the previous batch's (k+16)-mer counts, if it left any: the counters are as of a poll that came after
+    // its last launch (every launch sets `pending`), so an empty table is known to be empty
+    { int rc = settle_sk_polled(c); if (rc) return rc; }
     c->recovered = false;
     c->sorted_valid = false;
     c->st.n_reads += n_reads;

@@ -6,7 +6,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
 kmc = importlib.import_module("k-mer-count_amd")
 s = kmc.Synth(seed=2)
-n, _ = kmc.synth_records_for_bytes(s, int(10e9))
+n, _ = kmc.synth_records_for_bytes(s, int(float(sys.argv[1]) if len(sys.argv) > 1 else 10e9))
 d_b = torch.empty(n * 400 + 64, dtype=torch.uint8, device="cuda"); d_o = torch.empty(n + 1, dtype=torch.int64, device="cuda")
 kmc.synth_reads_device(s, 0, n, d_b.data_ptr(), d_o.data_ptr()); torch.cuda.synchronize()
 kc = kmc.KmerCounter(k=31)
