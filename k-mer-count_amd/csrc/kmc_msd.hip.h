@@ -547,10 +547,19 @@ __global__ void kmc_msd_order_kernel(const MsdTerm* __restrict__ term, u32 n_ter
 // nd[t] = their number.  kmc_msd_gather_kernel then makes the run dense.
 template <int KW, bool WEIGHTS> struct MsdLeafLds {
     static constexpr int CAP = KW == 1 ? KMC_MSD_LEAF1 : (WEIGHTS ? KMC_MSD_LEAF2W : KMC_MSD_LEAF2);
-    u64 a_lo[CAP], b_lo[CAP];
-    u64 a_hi[KW == 2 ? CAP : 1], b_hi[KW == 2 ? CAP : 1];
-    u64 a_w[WEIGHTS ? CAP : 1], b_w[WEIGHTS ? CAP : 1];   // weights (counts) of the keys
-    u32 cnt[KMC_MSD_LEAF_NSB], off[KMC_MSD_LEAF_NSB + 1];
+    // ONE image of the leaf (the keys come in through registers: with a second image a one-word leaf took
+    // 36 KB and four leaves fit a CU; now five do).  A large sub-bucket is split through a small per-wave
+    // scratch; what does not fit there goes through the terminal's own span of the OTHER key buffer in global
+    // memory, dead until the pairs are staged there (agent-scope fences: slow, rare).
+    u64 b_lo[CAP];
+    u64 b_hi[KW == 2 ? CAP : 1];
+    u64 b_w[WEIGHTS ? CAP : 1];   // weights (counts) of the keys
+    // a wave's scratch for a large sub-bucket (8 KB per workgroup in all; larger sub-buckets use the global scratch)
+    static constexpr int SCR = (KW == 1 && !WEIGHTS) ? 256 : ((KW == 2 && WEIGHTS) ? 64 : 128);  // (128 for one-word keys: no faster on random keys, LR leaves 0.41 -> 0.65 ms)
+    u64 s_lo[4][SCR];
+    u64 s_hi[KW == 2 ? 4 : 1][KW == 2 ? SCR : 1];
+    u64 s_w[WEIGHTS ? 4 : 1][WEIGHTS ? SCR : 1];
+    u32 cnt[KMC_MSD_LEAF_NSB], off[KMC_MSD_LEAF_NSB + 1];   // (later: the run heads' positions, 16 bits each)
     u32 big[KMC_MSD_LEAF1 / KMC_MSD_THREAD_SORT + 4];     // sub-buckets too large for one thread
     u32 woff[4][132];                                     // a wave's own offsets when it splits such a sub-bucket again (its counters: cnt)
     u32 nbig;
@@ -599,14 +608,23 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     //    actual key range.  (A leaf may hold several children of its parent; the first version took the 8
     //    bits below the highest DIFFERING bit -- for a leaf that straddles a power of two, e.g. children
     //    0111111111 and 1000000000, that put all keys into two sub-buckets: 65 of the sort's 97 ms.)
+    constexpr int PER = MsdLeafLds<KW, WEIGHTS>::CAP / KMC_MSD_THREADS;  // keys per thread, in registers
+    u64 rlo[PER], rhi[KW == 2 ? PER : 1], rw[WEIGHTS ? PER : 1];
     u64 mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
-    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
-        const u64 lo = klo[T.begin + i], hi = KW == 2 ? khi[T.begin + i] : 0ull;
-        L.a_lo[i] = lo;
-        if (KW == 2) L.a_hi[i] = hi;
-        if (WEIGHTS) L.a_w[i] = kw[T.begin + i];
-        if (key_less(hi, lo, mnh, mnl)) { mnh = hi; mnl = lo; }
-        if (key_less(mxh, mxl, hi, lo)) { mxh = hi; mxl = lo; }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const u32 i = tid + KMC_MSD_THREADS * e;
+        rlo[e] = 0;
+        if (KW == 2) rhi[e] = 0;
+        if (WEIGHTS) rw[e] = 0;
+        if (i < n) {
+            const u64 lo = klo[T.begin + i], hi = KW == 2 ? khi[T.begin + i] : 0ull;
+            rlo[e] = lo;
+            if (KW == 2) rhi[e] = hi;
+            if (WEIGHTS) rw[e] = kw[T.begin + i];
+            if (key_less(hi, lo, mnh, mnl)) { mnh = hi; mnl = lo; }
+            if (key_less(mxh, mxl, hi, lo)) { mxh = hi; mxl = lo; }
+        }
     }
     for (u32 i = tid; i < KMC_MSD_LEAF_NSB; i += KMC_MSD_THREADS) L.cnt[i] = 0;
     if (tid == 0) { L.bad = 0; L.n_out = 0; L.nbig = 0; }
@@ -633,7 +651,8 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         if (WEIGHTS) {
             __syncthreads();
             sw = 0;
-            for (u32 i = tid; i < n; i += KMC_MSD_THREADS) sw += L.a_w[i];
+#pragma unroll
+            for (int e = 0; e < PER; ++e) if (tid + KMC_MSD_THREADS * e < n) sw += rw[e];
             sw = wave_sum_u64(sw);
             if (lane == 0) L.sx[wv][0] = sw;
             __syncthreads();
@@ -656,7 +675,12 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         return (u32)((dl >> shift) | (dh << (64 - shift)));
     };
     // 2. LDS pass: a -> b grouped by digit
-    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) atomicAdd(&L.cnt[bucket(KW == 2 ? L.a_hi[i] : 0ull, L.a_lo[i]) & (KMC_MSD_LEAF_NSB - 1u)], 1u);
+    u32 rb[PER];  // sub-bucket of my keys
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        rb[e] = bucket(KW == 2 ? rhi[e] : 0ull, rlo[e]) & (KMC_MSD_LEAF_NSB - 1u);
+        if (tid + KMC_MSD_THREADS * e < n) atomicAdd(&L.cnt[rb[e]], 1u);
+    }
     __syncthreads();
     {   // exclusive prefix of the sub-bucket sizes: four consecutive sub-buckets per thread
         constexpr int PT = KMC_MSD_LEAF_NSB / KMC_MSD_THREADS;
@@ -680,12 +704,14 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         if (tid == KMC_MSD_THREADS - 1) L.off[KMC_MSD_LEAF_NSB] = run;
         __syncthreads();
     }
-    for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
-        const u64 lo = L.a_lo[i], hi = KW == 2 ? L.a_hi[i] : 0ull;
-        const u32 p = atomicAdd(&L.cnt[bucket(hi, lo) & (KMC_MSD_LEAF_NSB - 1u)], 1u);
-        L.b_lo[p] = lo;
-        if (KW == 2) L.b_hi[p] = hi;
-        if (WEIGHTS) L.b_w[p] = L.a_w[i];
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        if (tid + KMC_MSD_THREADS * e < n) {
+            const u32 p = atomicAdd(&L.cnt[rb[e]], 1u);
+            L.b_lo[p] = rlo[e];
+            if (KW == 2) L.b_hi[p] = rhi[e];
+            if (WEIGHTS) L.b_w[p] = rw[e];
+        }
     }
     __syncthreads();
     // 3a. every thread insertion-sorts its four sub-buckets in place (three keys each on average)
@@ -745,11 +771,11 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             if (have) { d_lo[rk] = lo; if (KW == 2) d_hi[rk] = hi; if (WEIGHTS) d_w[rk] = w; }
         }
     };
-    auto wave_sync = [&]() {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
+    // scratch: this terminal's span of the other key buffer and of t_cnt (nothing lives there until the pairs
+    // are staged at the end)
+    u64* const g_lo = t_lo + T.begin;
+    u64* const g_hi = KW == 2 ? t_hi + T.begin : nullptr;
+    u64* const g_w = t_cnt + T.begin;
     const u32 nbig = L.nbig;
     for (u32 bi = wv; bi < nbig; bi += 4) {
         const u32 d = L.big[bi];
@@ -780,13 +806,30 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             if (sh2 == 0) return (u32)dl & 127u;
             return (u32)((dl >> sh2) | (dh << (64 - sh2))) & 127u;
         };
+        // scratch of this sub-bucket, indexed like b (o .. o + m): the wave's LDS scratch, or global memory
+        constexpr u32 SCR = (u32)MsdLeafLds<KW, WEIGHTS>::SCR;
+        const bool use_g = m > SCR;
+        u64* const x_lo = use_g ? g_lo : (&L.s_lo[wv][0] - o);
+        u64* const x_hi = KW == 2 ? (use_g ? g_hi : (&L.s_hi[wv][0] - o)) : nullptr;
+        u64* const x_w = WEIGHTS ? (use_g ? g_w : (&L.s_w[wv][0] - o)) : nullptr;
+        auto xsync = [&]() {
+            if (use_g) {   // (global memory written and read by different lanes of the wave)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            } else {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        };
         u32* const wc = &L.cnt[wv * 128];   // (the leaf's own cursors are dead by now)
         u32* const wo = L.woff[wv];
 #pragma unroll
         for (int e = 0; e < 2; ++e) wc[lane * 2 + e] = 0;
-        wave_sync();
+        xsync();
         for (u32 i = lane; i < m; i += 64) atomicAdd(&wc[bkt2(KW == 2 ? L.b_hi[o + i] : 0ull, L.b_lo[o + i])], 1u);
-        wave_sync();
+        xsync();
         {
             u32 c4[2], mine = 0;
 #pragma unroll
@@ -799,15 +842,15 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             for (int e = 0; e < 2; ++e) { wo[lane * 2 + e] = run; wc[lane * 2 + e] = run; run += c4[e]; }
             if (lane == 63) wo[128] = run;
         }
-        wave_sync();
+        xsync();
         for (u32 i = lane; i < m; i += 64) {
             const u64 lo = L.b_lo[o + i], hi = KW == 2 ? L.b_hi[o + i] : 0ull;
             const u32 pp = atomicAdd(&wc[bkt2(hi, lo)], 1u);
-            L.a_lo[o + pp] = lo;
-            if (KW == 2) L.a_hi[o + pp] = hi;
-            if (WEIGHTS) L.a_w[o + pp] = L.b_w[o + i];
+            x_lo[o + pp] = lo;
+            if (KW == 2) x_hi[o + pp] = hi;
+            if (WEIGHTS) x_w[o + pp] = L.b_w[o + i];
         }
-        wave_sync();
+        xsync();
         // every lane: its two parts, insertion sort in a; parts that are still large are left for the wave
         u32 big_mask = 0;
 #pragma unroll
@@ -815,22 +858,22 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             const u32 oo = o + wo[lane * 2 + e], mm = wo[lane * 2 + e + 1] - wo[lane * 2 + e];
             if (mm > KMC_MSD_THREAD_SORT) { big_mask |= 1u << e; continue; }
             for (u32 i = 1; i < mm; ++i) {
-                const u64 lo = L.a_lo[oo + i], hi = KW == 2 ? L.a_hi[oo + i] : 0ull;
+                const u64 lo = x_lo[oo + i], hi = KW == 2 ? x_hi[oo + i] : 0ull;
                 u64 w = 0;
-                if (WEIGHTS) w = L.a_w[oo + i];
+                if (WEIGHTS) w = x_w[oo + i];
                 u32 j = i;
                 while (j > 0) {
-                    const u64 pl = L.a_lo[oo + j - 1], ph = KW == 2 ? L.a_hi[oo + j - 1] : 0ull;
+                    const u64 pl = x_lo[oo + j - 1], ph = KW == 2 ? x_hi[oo + j - 1] : 0ull;
                     if (!key_less(hi, lo, ph, pl)) break;
-                    L.a_lo[oo + j] = pl;
-                    if (KW == 2) L.a_hi[oo + j] = ph;
-                    if (WEIGHTS) L.a_w[oo + j] = L.a_w[oo + j - 1];
+                    x_lo[oo + j] = pl;
+                    if (KW == 2) x_hi[oo + j] = ph;
+                    if (WEIGHTS) x_w[oo + j] = x_w[oo + j - 1];
                     --j;
                 }
-                if (j != i) { L.a_lo[oo + j] = lo; if (KW == 2) L.a_hi[oo + j] = hi; if (WEIGHTS) L.a_w[oo + j] = w; }
+                if (j != i) { x_lo[oo + j] = lo; if (KW == 2) x_hi[oo + j] = hi; if (WEIGHTS) x_w[oo + j] = w; }
             }
         }
-        wave_sync();
+        xsync();
         // parts that are still large: one repeated key (nothing to do), or all-pairs a -> b -> a
         unsigned long long todo;
         while ((todo = __builtin_amdgcn_ballot_w64(big_mask != 0)) != 0) {
@@ -840,34 +883,33 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             const u32 oo = o + wo[src_lane * 2 + e];
             const u32 mm = wo[src_lane * 2 + e + 1] - wo[src_lane * 2 + e];
             if ((int)lane == src_lane) big_mask &= ~(1u << e);
-            const u64 plo = L.a_lo[oo], phi = KW == 2 ? L.a_hi[oo] : 0ull;
+            const u64 plo = x_lo[oo], phi = KW == 2 ? x_hi[oo] : 0ull;
             bool diff = false;
-            for (u32 i = lane; i < mm; i += 64) diff |= L.a_lo[oo + i] != plo || (KW == 2 && L.a_hi[oo + i] != phi);
+            for (u32 i = lane; i < mm; i += 64) diff |= x_lo[oo + i] != plo || (KW == 2 && x_hi[oo + i] != phi);
             if (__builtin_amdgcn_ballot_w64(diff) == 0) continue;
             if (mm > 1024) { if (lane == 0) L.bad = 1; continue; }
-            allpairs(&L.a_lo[oo], KW == 2 ? &L.a_hi[oo] : nullptr, WEIGHTS ? &L.a_w[oo] : nullptr,
+            allpairs(x_lo + oo, KW == 2 ? x_hi + oo : nullptr, WEIGHTS ? x_w + oo : nullptr,
                      &L.b_lo[oo], KW == 2 ? &L.b_hi[oo] : nullptr, WEIGHTS ? &L.b_w[oo] : nullptr, mm);
-            wave_sync();
-            for (u32 i = lane; i < mm; i += 64) { L.a_lo[oo + i] = L.b_lo[oo + i]; if (KW == 2) L.a_hi[oo + i] = L.b_hi[oo + i]; if (WEIGHTS) L.a_w[oo + i] = L.b_w[oo + i]; }
-            wave_sync();
+            xsync();
+            for (u32 i = lane; i < mm; i += 64) { x_lo[oo + i] = L.b_lo[oo + i]; if (KW == 2) x_hi[oo + i] = L.b_hi[oo + i]; if (WEIGHTS) x_w[oo + i] = L.b_w[oo + i]; }
+            xsync();
         }
         for (u32 i = lane; i < m; i += 64) {       // back into b (this wave's own sub-bucket)
-            L.b_lo[o + i] = L.a_lo[o + i];
-            if (KW == 2) L.b_hi[o + i] = L.a_hi[o + i];
-            if (WEIGHTS) L.b_w[o + i] = L.a_w[o + i];
+            L.b_lo[o + i] = x_lo[o + i];
+            if (KW == 2) L.b_hi[o + i] = x_hi[o + i];
+            if (WEIGHTS) L.b_w[o + i] = x_w[o + i];
         }
     }
     __syncthreads();
     if (L.bad) {
         // a sub-bucket of more than 1024 keys that differ (heavily repeated keys next to others): sort
-        // the whole leaf with a bitonic network in LDS (rare).  Source b, network in a, result back in b.
+        // the whole leaf with a bitonic network in LDS (rare), in place, padded to a power of two.
         u32 P = 1;
         while (P < n) P <<= 1;
-        for (u32 i = tid; i < P; i += KMC_MSD_THREADS) {
-            const bool in = i < n;
-            L.a_lo[i] = in ? L.b_lo[i] : ~0ull;
-            if (KW == 2) L.a_hi[i] = in ? L.b_hi[i] : ~0ull;
-            if (WEIGHTS) L.a_w[i] = in ? L.b_w[i] : 0ull;
+        for (u32 i = n + tid; i < P; i += KMC_MSD_THREADS) {
+            L.b_lo[i] = ~0ull;
+            if (KW == 2) L.b_hi[i] = ~0ull;
+            if (WEIGHTS) L.b_w[i] = 0ull;
         }
         __syncthreads();
         for (u32 kk = 2; kk <= P; kk <<= 1) {
@@ -875,32 +917,27 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
                 for (u32 i = tid; i < P; i += KMC_MSD_THREADS) {
                     const u32 ix = i ^ jj;
                     if (ix > i) {
-                        const u64 al = L.a_lo[i], bl = L.a_lo[ix];
-                        const u64 ah = KW == 2 ? L.a_hi[i] : 0ull, bh = KW == 2 ? L.a_hi[ix] : 0ull;
+                        const u64 al = L.b_lo[i], bl = L.b_lo[ix];
+                        const u64 ah = KW == 2 ? L.b_hi[i] : 0ull, bh = KW == 2 ? L.b_hi[ix] : 0ull;
                         const bool up = (i & kk) == 0;
                         const bool sw = up ? key_less(bh, bl, ah, al) : key_less(ah, al, bh, bl);
                         if (sw) {
-                            L.a_lo[i] = bl; L.a_lo[ix] = al;
-                            if (KW == 2) { L.a_hi[i] = bh; L.a_hi[ix] = ah; }
-                            if (WEIGHTS) { const u64 wa = L.a_w[i]; L.a_w[i] = L.a_w[ix]; L.a_w[ix] = wa; }
+                            L.b_lo[i] = bl; L.b_lo[ix] = al;
+                            if (KW == 2) { L.b_hi[i] = bh; L.b_hi[ix] = ah; }
+                            if (WEIGHTS) { const u64 wa = L.b_w[i]; L.b_w[i] = L.b_w[ix]; L.b_w[ix] = wa; }
                         }
                     }
                 }
                 __syncthreads();
             }
         }
-        for (u32 i = tid; i < n; i += KMC_MSD_THREADS) {
-            L.b_lo[i] = L.a_lo[i];
-            if (KW == 2) L.b_hi[i] = L.a_hi[i];
-            if (WEIGHTS) L.b_w[i] = L.a_w[i];
-        }
-        __syncthreads();
     }
     // 4. run-length over the sorted image b[0..n).  Phase 1: the position of every run head, compacted
-    //    (a_lo is free by now and holds the list); phase 2: one thread per run -- its length is the distance
+    //    (16 bits each, in the space of the sub-bucket counters and offsets, dead by now); phase 2: one thread per run -- its length is the distance
     //    to the next head (the first version let the head's thread walk its run: one thread, thousands of
     //    dependent LDS reads for a key with thousands of copies, everybody else waiting at the barrier).
-    u32* const hidx = reinterpret_cast<u32*>(L.a_lo);
+    static_assert(sizeof(L.cnt) + sizeof(L.off) >= MsdLeafLds<KW, WEIGHTS>::CAP * sizeof(unsigned short), "run-head list does not fit");
+    unsigned short* const hidx = reinterpret_cast<unsigned short*>(L.cnt);
     for (u32 c0 = 0; c0 < n; c0 += KMC_MSD_THREADS * 4) {
         const u32 i0 = c0 + tid * 4;  // each thread owns 4 consecutive elements of this slab
         u32 nh = 0;
@@ -923,7 +960,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         for (u32 w = 0; w < wv; ++w) wbase += L.wsum[w];
         u32 pos = wbase + inc - nh;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) if (i0 + e < n && head[e]) hidx[pos++] = i0 + e;
+        for (int e = 0; e < 4; ++e) if (i0 + e < n && head[e]) hidx[pos++] = (unsigned short)(i0 + e);
         __syncthreads();
         if (tid == KMC_MSD_THREADS - 1) L.n_out = pos;  // (the last thread's end = the slab's end)
         __syncthreads();
