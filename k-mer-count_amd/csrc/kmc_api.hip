@@ -86,6 +86,7 @@ struct kmc_ctx {
     std::vector<Run> run_pool;   // buffers of dropped runs, reused (multi-GB hipMalloc/hipFree per batch is slow)
     Run view_run;                // the merged, sorted view built by the last kmc_finalize (table entries + runs)
     const u64 *v_hi = nullptr, *v_lo = nullptr, *v_cnt = nullptr;  // the sorted view of the last finalize
+    bool msd_dup_heavy = false;  // the last large unweighted sort collapsed its keys more than fourfold (leaf size of two-word sorts)
     bool prefer_sort = false;  // AUTO: the data source proved high-cardinality  // per-workgroup memo slots, kept across launches (kmc_walk.hip.h)
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the whole batch
@@ -564,7 +565,11 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     if (!n) return KMC_OK;
     if (n >= (1ull << 32) - KMC_MSD_RANGE) return fail(c, KMC_ERR_ARG, "msd sort: more than 2^32 keys in one pass");
     const bool weights = w[0] != nullptr;
-    const u32 leaf_cap = KW == 1 ? KMC_MSD_LEAF1 : (w[0] ? KMC_MSD_LEAF2W : KMC_MSD_LEAF2);
+    // two-word keys: leaves of 2048 keys save a level on random keys (1270 keys per child after two levels:
+    // 84 -> 57 ms for 760 M 63-mers) but cost on heavily repeated, clustered keys (pool = 1000: 87 -> 102 ms);
+    // a ctx whose last sort collapsed its keys more than fourfold keeps the smaller leaves
+    u32 leaf_cap = KW == 1 ? KMC_MSD_LEAF1 : (w[0] ? KMC_MSD_LEAF2W : KMC_MSD_LEAF2);
+    if (KW == 2 && !w[0] && c->msd_dup_heavy) leaf_cap = 1024;
     const u64 max_seg = n / leaf_cap + 257;
     const u64 max_ranges = n / KMC_MSD_RANGE + max_seg + 1;
     const u64 term_cap = 16 * (n / leaf_cap) + 65536;
@@ -645,16 +650,18 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     hipLaunchKernelGGL(kmc_msd_order_kernel, dim3(grid_for(c, n_term, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_term.p, n_term,
                        (const unsigned long long*)c->m_bitmap.p, (const u32*)c->m_rank.p, (MsdTerm*)c->m_ord.p);
     u64* t_cnt0 = (u64*)c->m_cnt.p;  // pair staging: counts (keys are staged in the key buffers themselves)
-#define MSD_LEAF(KWV, WV)                                                                                                                   \
+#define MSD_LEAF(KWV, WV, CAPV)                                                                                                             \
     do {                                                                                                                                    \
         static bool attr = false;                                                                                                           \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_msd_leaf_kernel<KWV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdLeafLds<KWV, WV>)); attr = true; } \
-        hipLaunchKernelGGL((kmc_msd_leaf_kernel<KWV, WV>), dim3(n_term), dim3(KMC_MSD_THREADS), sizeof(MsdLeafLds<KWV, WV>), c->stream,           \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_msd_leaf_kernel<KWV, WV, CAPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdLeafLds<KWV, WV, CAPV>)); attr = true; } \
+        hipLaunchKernelGGL((kmc_msd_leaf_kernel<KWV, WV, CAPV>), dim3(n_term), dim3(KMC_MSD_THREADS), sizeof(MsdLeafLds<KWV, WV, CAPV>), c->stream,   \
                            (const u64*)hi[0], (const u64*)lo[0], (const u64*)(weights ? w[0] : nullptr), (const u64*)hi[1], (const u64*)lo[1], (const u64*)(weights ? w[1] : nullptr), \
                            (const MsdTerm*)c->m_ord.p, n_term, (int)kb, hi[0], lo[0], hi[1], lo[1], t_cnt0, (u32*)c->m_nd.p, ctl); \
     } while (0)
-    if (KW == 1) { if (weights) MSD_LEAF(1, true); else MSD_LEAF(1, false); }
-    else { if (weights) MSD_LEAF(2, true); else MSD_LEAF(2, false); }
+    if (KW == 1) { if (weights) MSD_LEAF(1, true, KMC_MSD_LEAF1); else MSD_LEAF(1, false, KMC_MSD_LEAF1); }
+    else if (weights) MSD_LEAF(2, true, KMC_MSD_LEAF2W);
+    else if (leaf_cap > 1024) MSD_LEAF(2, false, KMC_MSD_LEAF2);
+    else MSD_LEAF(2, false, 1024);
 #undef MSD_LEAF
     {   // base[t] = exclusive prefix of the terminals' pair counts
         const u32 nb = (n_term + KMC_SCAN_PER_BLOCK - 1) / KMC_SCAN_PER_BLOCK;
@@ -672,6 +679,7 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     run.n = n_pairs;
     run.total = weights ? (u64)c->h_ctl->w_total : (u64)c->h_ctl->n_valid;  // what the run's counts sum to
     run.total_known = true;
+    if (!weights && c->h_ctl->n_valid >= (1u << 20)) c->msd_dup_heavy = (u64)c->h_ctl->n_valid >= 4 * std::max<u64>(n_pairs, 1);
     if (KW == 1) hipLaunchKernelGGL(kmc_msd_gather_kernel<1>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, (const u32*)c->m_nd.p, (const u32*)c->m_base.p,
                                     (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1], (const u64*)t_cnt0, run.hi, run.lo, run.cnt);
     else hipLaunchKernelGGL(kmc_msd_gather_kernel<2>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, (const u32*)c->m_nd.p, (const u32*)c->m_base.p,
@@ -1643,6 +1651,7 @@ static int kmc_forget_source_impl(kmc_ctx* c, int what) {
         c->rho_hist = -1.0;
         c->rho_last = c->rho_max = 0.0;
         c->prefer_sort = false;
+        c->msd_dup_heavy = false;
         c->walk_overflowed = false;
     }
     return KMC_OK;

@@ -36,7 +36,7 @@
 #define KMC_MSD_THREADS 256
 #define KMC_MSD_LEAF1 2048    // leaf capacity, one-word keys  (two LDS images of 16 KB: four leaves per CU in flight)
 #ifndef KMC_MSD_LEAF2
-#define KMC_MSD_LEAF2 1024    // leaf capacity, two-word keys without weights (2048: random 63-mers 88 -> 66 ms, but clustered keys 90 -> 112 ms and the LR mode 8.1 -> 9.2 ms)
+#define KMC_MSD_LEAF2 2048    // leaf capacity, two-word keys without weights
 #endif
 #define KMC_MSD_LEAF2W 1024   // leaf capacity, two-word keys with weights
 #define KMC_MSD_THREAD_SORT 32  // sub-buckets up to this size are insertion-sorted by one thread
@@ -545,8 +545,8 @@ __global__ void kmc_msd_order_kernel(const MsdTerm* __restrict__ term, u32 n_ter
 // One workgroup per terminal (in position order).  Result: the terminal's (key, count) pairs, sorted,
 // written at the terminal's own positions of the OTHER key buffer (dead there) and of t_cnt, and
 // nd[t] = their number.  kmc_msd_gather_kernel then makes the run dense.
-template <int KW, bool WEIGHTS> struct MsdLeafLds {
-    static constexpr int CAP = KW == 1 ? KMC_MSD_LEAF1 : (WEIGHTS ? KMC_MSD_LEAF2W : KMC_MSD_LEAF2);
+template <int KW, bool WEIGHTS, int CAPV> struct MsdLeafLds {
+    static constexpr int CAP = CAPV;   // leaf capacity (KMC_MSD_LEAF1 / LEAF2 / LEAF2W; two-word sorts also run with 1024)
     // ONE image of the leaf (the keys come in through registers: with a second image a one-word leaf took
     // 36 KB and four leaves fit a CU; now five do).  A large sub-bucket is split through a small per-wave
     // scratch; what does not fit there goes through the terminal's own span of the OTHER key buffer in global
@@ -555,7 +555,7 @@ template <int KW, bool WEIGHTS> struct MsdLeafLds {
     u64 b_hi[KW == 2 ? CAP : 1];
     u64 b_w[WEIGHTS ? CAP : 1];   // weights (counts) of the keys
     // a wave's scratch for a large sub-bucket (8 KB per workgroup in all; larger sub-buckets use the global scratch)
-    static constexpr int SCR = (KW == 1 && !WEIGHTS) ? 256 : ((KW == 2 && WEIGHTS) ? 64 : 128);  // (128 for one-word keys: no faster on random keys, LR leaves 0.41 -> 0.65 ms)
+    static constexpr int SCR = (KW == 1 && !WEIGHTS) ? 256 : ((KW == 2 && WEIGHTS) ? 64 : ((KW == 2 && CAPV > 1024) ? 192 : 128));  // (128 for one-word keys: no faster on random keys, LR leaves 0.41 -> 0.65 ms)
     u64 s_lo[4][SCR];
     u64 s_hi[KW == 2 ? 4 : 1][KW == 2 ? SCR : 1];
     u64 s_w[WEIGHTS ? 4 : 1][WEIGHTS ? SCR : 1];
@@ -569,7 +569,7 @@ template <int KW, bool WEIGHTS> struct MsdLeafLds {
     u64 sx[4][2], sy[4][2];
 };
 
-template <int KW, bool WEIGHTS>
+template <int KW, bool WEIGHTS, int CAPV>
 __global__ __launch_bounds__(KMC_MSD_THREADS)
 void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo0, const u64* __restrict__ w0,
                          const u64* __restrict__ hi1, const u64* __restrict__ lo1, const u64* __restrict__ w1,
@@ -577,7 +577,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
                          u64* __restrict__ s_hi0, u64* __restrict__ s_lo0, u64* __restrict__ s_hi1, u64* __restrict__ s_lo1,
                          u64* __restrict__ t_cnt, u32* __restrict__ nd, MsdCtl* __restrict__ ctl) {
     extern __shared__ __align__(16) unsigned char msd_smem[];
-    MsdLeafLds<KW, WEIGHTS>& L = *reinterpret_cast<MsdLeafLds<KW, WEIGHTS>*>(msd_smem);
+    MsdLeafLds<KW, WEIGHTS, CAPV>& L = *reinterpret_cast<MsdLeafLds<KW, WEIGHTS, CAPV>*>(msd_smem);
     const u32 t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const MsdTerm T = term[t];
     const u64* khi = T.parity ? hi1 : hi0;
@@ -608,7 +608,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     //    actual key range.  (A leaf may hold several children of its parent; the first version took the 8
     //    bits below the highest DIFFERING bit -- for a leaf that straddles a power of two, e.g. children
     //    0111111111 and 1000000000, that put all keys into two sub-buckets: 65 of the sort's 97 ms.)
-    constexpr int PER = MsdLeafLds<KW, WEIGHTS>::CAP / KMC_MSD_THREADS;  // keys per thread, in registers
+    constexpr int PER = MsdLeafLds<KW, WEIGHTS, CAPV>::CAP / KMC_MSD_THREADS;  // keys per thread, in registers
     u64 rlo[PER], rhi[KW == 2 ? PER : 1], rw[WEIGHTS ? PER : 1];
     u64 mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
 #pragma unroll
@@ -807,7 +807,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             return (u32)((dl >> sh2) | (dh << (64 - sh2))) & 127u;
         };
         // scratch of this sub-bucket, indexed like b (o .. o + m): the wave's LDS scratch, or global memory
-        constexpr u32 SCR = (u32)MsdLeafLds<KW, WEIGHTS>::SCR;
+        constexpr u32 SCR = (u32)MsdLeafLds<KW, WEIGHTS, CAPV>::SCR;
         const bool use_g = m > SCR;
         u64* const x_lo = use_g ? g_lo : (&L.s_lo[wv][0] - o);
         u64* const x_hi = KW == 2 ? (use_g ? g_hi : (&L.s_hi[wv][0] - o)) : nullptr;
@@ -936,7 +936,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     //    (16 bits each, in the space of the sub-bucket counters and offsets, dead by now); phase 2: one thread per run -- its length is the distance
     //    to the next head (the first version let the head's thread walk its run: one thread, thousands of
     //    dependent LDS reads for a key with thousands of copies, everybody else waiting at the barrier).
-    static_assert(sizeof(L.cnt) + sizeof(L.off) >= MsdLeafLds<KW, WEIGHTS>::CAP * sizeof(unsigned short), "run-head list does not fit");
+    static_assert(sizeof(L.cnt) + sizeof(L.off) >= MsdLeafLds<KW, WEIGHTS, CAPV>::CAP * sizeof(unsigned short), "run-head list does not fit");
     unsigned short* const hidx = reinterpret_cast<unsigned short*>(L.cnt);
     for (u32 c0 = 0; c0 < n; c0 += KMC_MSD_THREADS * 4) {
         const u32 i0 = c0 + tid * 4;  // each thread owns 4 consecutive elements of this slab
