@@ -914,6 +914,25 @@ def test_msd_sort_path_matches_oracle(kmc, oracle, k, pool, n_rec):
         assert kc.export().equals(oracle.count_kmers(hb, ho, k, True, method=1))
 
 
+def test_two_word_sort_with_both_leaf_sizes(kmc, oracle):
+    """Two-word keys are sorted with leaves of 2048 keys -- until a sort of the ctx has collapsed its keys more
+    than fourfold (heavily repeated keys: the smaller leaves are faster there), after which it uses leaves of
+    1024 (kmc_msd_leaf_kernel<2, false, 1024>).  Both instantiations must give the oracle's table: the same ctx
+    sorts a repetitive batch (sets the flag), the same batch again (small leaves), then a random one."""
+    k = 63
+    rep_b, rep_o = kmc.synth_reads_host(kmc.Synth(seed=5, pool=40), 0, 6000)    # 2.0 M k-mers, ~60 k distinct
+    rnd_b, rnd_o = kmc.synth_reads_host(kmc.Synth(seed=6, pool=0), 0, 6000)     # 2.0 M k-mers, all distinct
+    want_rep = oracle.count_kmers(rep_b, rep_o, k, True, method=1)
+    want_rnd = oracle.count_kmers(rnd_b, rnd_o, k, True, method=1)
+    assert want_rep.n_total >= (1 << 20) and want_rep.n_total >= 4 * want_rep.n_distinct
+    with kmc.KmerCounter(k=k, algo=kmc.ALGO_SORT) as kc:
+        for hb, ho, want in ((rep_b, rep_o, want_rep), (rep_b, rep_o, want_rep), (rnd_b, rnd_o, want_rnd), (rnd_b, rnd_o, want_rnd)):
+            kc.reset()
+            kc.add_batch(hb, ho)
+            assert kc.export().equals(want)
+            assert kc.stats().algo_last == kmc.ALGO_SORT
+
+
 @pytest.mark.parametrize("algo_name", ["auto", "walk", "stream"])
 def test_wrong_prediction_is_recovered_not_fatal(kmc, oracle, algo_name):
     """The launch planner sizes a batch's launches from what earlier batches (and earlier launches of the
