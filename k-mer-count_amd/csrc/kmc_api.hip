@@ -622,8 +622,8 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
                            next, (u32)max_seg, (MsdTerm*)c->m_term.p, (u32)term_cap, (unsigned long long*)c->m_bitmap.p, ctl);
 #define MSD_SCATTER(KWV, WV)                                                                                                              \
         do {                                                                                                                              \
-            static bool attr = false;                                                                                                     \
-            if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_msd_scatter_kernel<KWV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdScatterLds<KWV, WV>)); attr = true; } \
+            static std::atomic<unsigned long long> attr{0};                                                                               \
+            if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_msd_scatter_kernel<KWV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdScatterLds<KWV, WV>)); \
             hipLaunchKernelGGL((kmc_msd_scatter_kernel<KWV, WV>), dim3(grid), dim3(1024), sizeof(MsdScatterLds<KWV, WV>), c->stream, hi[0], lo[0], w[0], hi[1], lo[1], w[1], \
                                (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)c->m_hist.p, (const u32*)c->m_cbase.p, (const u32*)c->m_skip.p, \
                                (int)kb, l == 0 ? 1 : 0, (const MsdCtl*)ctl);                                                 \
@@ -652,8 +652,8 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     u64* t_cnt0 = (u64*)c->m_cnt.p;  // pair staging: counts (keys are staged in the key buffers themselves)
 #define MSD_LEAF(KWV, WV, CAPV)                                                                                                             \
     do {                                                                                                                                    \
-        static bool attr = false;                                                                                                           \
-        if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_msd_leaf_kernel<KWV, WV, CAPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdLeafLds<KWV, WV, CAPV>)); attr = true; } \
+        static std::atomic<unsigned long long> attr{0};                                                                                     \
+        if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_msd_leaf_kernel<KWV, WV, CAPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdLeafLds<KWV, WV, CAPV>)); \
         hipLaunchKernelGGL((kmc_msd_leaf_kernel<KWV, WV, CAPV>), dim3(n_term), dim3(KMC_MSD_THREADS), sizeof(MsdLeafLds<KWV, WV, CAPV>), c->stream,   \
                            (const u64*)hi[0], (const u64*)lo[0], (const u64*)(weights ? w[0] : nullptr), (const u64*)hi[1], (const u64*)lo[1], (const u64*)(weights ? w[1] : nullptr), \
                            (const MsdTerm*)c->m_ord.p, n_term, (int)kb, hi[0], lo[0], hi[1], lo[1], t_cnt0, (u32*)c->m_nd.p, ctl); \

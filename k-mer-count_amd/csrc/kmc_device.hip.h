@@ -238,3 +238,16 @@ __device__ __forceinline__ u64 wave_sum_u64(u64 v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+
+// hipFuncSetAttribute (dynamic LDS beyond 64 KB) is per DEVICE: one flag per (kernel instantiation, device), so
+// that a process with contexts on several GPUs (kmc_count_file_multi) sets it on each of them
+#include <atomic>
+static inline bool kmc_attr_once(std::atomic<unsigned long long>& done) {
+    int d = 0;
+    (void)hipGetDevice(&d);
+    const unsigned long long bit = 1ull << (d & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return false;
+    done.fetch_or(bit, std::memory_order_relaxed);
+    return true;
+}
+

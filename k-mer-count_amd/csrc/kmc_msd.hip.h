@@ -806,12 +806,14 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             if (sh2 == 0) return (u32)dl & 127u;
             return (u32)((dl >> sh2) | (dh << (64 - sh2))) & 127u;
         };
-        // scratch of this sub-bucket, indexed like b (o .. o + m): the wave's LDS scratch, or global memory
+        // scratch of this sub-bucket: the wave's LDS scratch (indexed 0 .. m) or global memory (indexed like b: o .. o + m);
+        // xo is what turns a b index into a scratch index
         constexpr u32 SCR = (u32)MsdLeafLds<KW, WEIGHTS, CAPV>::SCR;
         const bool use_g = m > SCR;
-        u64* const x_lo = use_g ? g_lo : (&L.s_lo[wv][0] - o);
-        u64* const x_hi = KW == 2 ? (use_g ? g_hi : (&L.s_hi[wv][0] - o)) : nullptr;
-        u64* const x_w = WEIGHTS ? (use_g ? g_w : (&L.s_w[wv][0] - o)) : nullptr;
+        const u32 xo = use_g ? 0u : o;
+        u64* const x_lo = use_g ? g_lo : &L.s_lo[wv][0];
+        u64* const x_hi = KW == 2 ? (use_g ? g_hi : &L.s_hi[wv][0]) : nullptr;
+        u64* const x_w = WEIGHTS ? (use_g ? g_w : &L.s_w[wv][0]) : nullptr;
         auto xsync = [&]() {
             if (use_g) {   // (global memory written and read by different lanes of the wave)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
@@ -846,9 +848,9 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         for (u32 i = lane; i < m; i += 64) {
             const u64 lo = L.b_lo[o + i], hi = KW == 2 ? L.b_hi[o + i] : 0ull;
             const u32 pp = atomicAdd(&wc[bkt2(hi, lo)], 1u);
-            x_lo[o + pp] = lo;
-            if (KW == 2) x_hi[o + pp] = hi;
-            if (WEIGHTS) x_w[o + pp] = L.b_w[o + i];
+            x_lo[(o + pp) - xo] = lo;
+            if (KW == 2) x_hi[(o + pp) - xo] = hi;
+            if (WEIGHTS) x_w[(o + pp) - xo] = L.b_w[o + i];
         }
         xsync();
         // every lane: its two parts, insertion sort in a; parts that are still large are left for the wave
@@ -858,19 +860,19 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             const u32 oo = o + wo[lane * 2 + e], mm = wo[lane * 2 + e + 1] - wo[lane * 2 + e];
             if (mm > KMC_MSD_THREAD_SORT) { big_mask |= 1u << e; continue; }
             for (u32 i = 1; i < mm; ++i) {
-                const u64 lo = x_lo[oo + i], hi = KW == 2 ? x_hi[oo + i] : 0ull;
+                const u64 lo = x_lo[(oo + i) - xo], hi = KW == 2 ? x_hi[(oo + i) - xo] : 0ull;
                 u64 w = 0;
-                if (WEIGHTS) w = x_w[oo + i];
+                if (WEIGHTS) w = x_w[(oo + i) - xo];
                 u32 j = i;
                 while (j > 0) {
-                    const u64 pl = x_lo[oo + j - 1], ph = KW == 2 ? x_hi[oo + j - 1] : 0ull;
+                    const u64 pl = x_lo[(oo + j - 1) - xo], ph = KW == 2 ? x_hi[(oo + j - 1) - xo] : 0ull;
                     if (!key_less(hi, lo, ph, pl)) break;
-                    x_lo[oo + j] = pl;
-                    if (KW == 2) x_hi[oo + j] = ph;
-                    if (WEIGHTS) x_w[oo + j] = x_w[oo + j - 1];
+                    x_lo[(oo + j) - xo] = pl;
+                    if (KW == 2) x_hi[(oo + j) - xo] = ph;
+                    if (WEIGHTS) x_w[(oo + j) - xo] = x_w[(oo + j - 1) - xo];
                     --j;
                 }
-                if (j != i) { x_lo[oo + j] = lo; if (KW == 2) x_hi[oo + j] = hi; if (WEIGHTS) x_w[oo + j] = w; }
+                if (j != i) { x_lo[(oo + j) - xo] = lo; if (KW == 2) x_hi[(oo + j) - xo] = hi; if (WEIGHTS) x_w[(oo + j) - xo] = w; }
             }
         }
         xsync();
@@ -883,21 +885,21 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             const u32 oo = o + wo[src_lane * 2 + e];
             const u32 mm = wo[src_lane * 2 + e + 1] - wo[src_lane * 2 + e];
             if ((int)lane == src_lane) big_mask &= ~(1u << e);
-            const u64 plo = x_lo[oo], phi = KW == 2 ? x_hi[oo] : 0ull;
+            const u64 plo = x_lo[(oo) - xo], phi = KW == 2 ? x_hi[(oo) - xo] : 0ull;
             bool diff = false;
-            for (u32 i = lane; i < mm; i += 64) diff |= x_lo[oo + i] != plo || (KW == 2 && x_hi[oo + i] != phi);
+            for (u32 i = lane; i < mm; i += 64) diff |= x_lo[(oo + i) - xo] != plo || (KW == 2 && x_hi[(oo + i) - xo] != phi);
             if (__builtin_amdgcn_ballot_w64(diff) == 0) continue;
             if (mm > 1024) { if (lane == 0) L.bad = 1; continue; }
-            allpairs(x_lo + oo, KW == 2 ? x_hi + oo : nullptr, WEIGHTS ? x_w + oo : nullptr,
+            allpairs(x_lo + (oo - xo), KW == 2 ? x_hi + (oo - xo) : nullptr, WEIGHTS ? x_w + (oo - xo) : nullptr,
                      &L.b_lo[oo], KW == 2 ? &L.b_hi[oo] : nullptr, WEIGHTS ? &L.b_w[oo] : nullptr, mm);
             xsync();
-            for (u32 i = lane; i < mm; i += 64) { x_lo[oo + i] = L.b_lo[oo + i]; if (KW == 2) x_hi[oo + i] = L.b_hi[oo + i]; if (WEIGHTS) x_w[oo + i] = L.b_w[oo + i]; }
+            for (u32 i = lane; i < mm; i += 64) { x_lo[(oo + i) - xo] = L.b_lo[oo + i]; if (KW == 2) x_hi[(oo + i) - xo] = L.b_hi[oo + i]; if (WEIGHTS) x_w[(oo + i) - xo] = L.b_w[oo + i]; }
             xsync();
         }
         for (u32 i = lane; i < m; i += 64) {       // back into b (this wave's own sub-bucket)
-            L.b_lo[o + i] = x_lo[o + i];
-            if (KW == 2) L.b_hi[o + i] = x_hi[o + i];
-            if (WEIGHTS) L.b_w[o + i] = x_w[o + i];
+            L.b_lo[o + i] = x_lo[(o + i) - xo];
+            if (KW == 2) L.b_hi[o + i] = x_hi[(o + i) - xo];
+            if (WEIGHTS) L.b_w[o + i] = x_w[(o + i) - xo];
         }
     }
     __syncthreads();

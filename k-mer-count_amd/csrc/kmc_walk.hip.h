@@ -943,8 +943,8 @@ template <int KW, bool CANON>
 static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const uint8_t* d_bases, const u64* d_vstart, const u64* d_vend,
                                      u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, u64* gcnt, void* memo, int parity, GTable g, GTable sk, int phase) {
     const size_t smem = sizeof(WalkLds<KW>);
-    static bool attr = false;  // one flag per instantiation
-    if (!attr) { (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<KW, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr = true; }
+    static std::atomic<unsigned long long> attr{0};  // one flag per instantiation and device
+    if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<KW, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     WalkMemoSlot<KW>* slots = (WalkMemoSlot<KW>*)memo;
     if (phase == 0) {
         hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_vstart, d_vend, n_reads, k, tile_begin, tile_end, hdr, list,
