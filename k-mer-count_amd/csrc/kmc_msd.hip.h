@@ -466,14 +466,15 @@ void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* _
         __syncthreads();
         // 1. my keys, their digits and their ranks within the tile
         u64 mlo[PER], mhi[PER], mw[PER];
-        u32 md[PER], mr[PER];
+        u32 md[PER];  // digit (11 bits) | rank within the tile << 11; ~0: no key  (one register per key: at 16 keys
+                      // per thread a second array spilled)
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             md[e] = ~0u;
             mlo[e] = nlo[e]; mhi[e] = nhi[e]; mw[e] = nw[e];
             if (tid + 1024u * e < tn) {
-                md[e] = (level0 && msd_is_filler<KW>(mhi[e], mlo[e], kb)) ? (u32)KMC_MSD_ND : (msd_bits<KW>(mhi[e], mlo[e], shift) & mask);
-                mr[e] = atomicAdd(&L.cnt[md[e]], 1u);
+                const u32 d = (level0 && msd_is_filler<KW>(mhi[e], mlo[e], kb)) ? (u32)KMC_MSD_ND : (msd_bits<KW>(mhi[e], mlo[e], shift) & mask);
+                md[e] = d | (atomicAdd(&L.cnt[d], 1u) << 11);
             }
         }
         if (t0 + TILE < n) {  // (block-uniform) next tile's loads go out now and land during steps 2-4
@@ -505,7 +506,7 @@ void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* _
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             if (md[e] != ~0u) {
-                const u32 p = L.cnt[md[e]] + mr[e];
+                const u32 p = L.cnt[md[e] & 2047u] + (md[e] >> 11);
                 L.lo[p] = mlo[e];
                 if (KW == 2) L.hi[p] = mhi[e];
                 if (WEIGHTS) L.w[p] = mw[e];
