@@ -621,6 +621,15 @@ def test_reference_mode_cli_and_errors(kmc, oracle, tmp_path):
         with pytest.raises(kmc.KmcError) as e:
             kc.finalize()
         assert e.value.status == kmc.ERR_ALPHABET
+    # ... but only where the reference looks (main.rs:17-23: the characters of the emitted chunks): a record of
+    # exactly 80 bases has ONE chunk, L = [0, 27) and R = [53, 80); an N in the gap between them is never seen
+    with kmc.KmerCounter(mode=kmc.MODE_LR) as kc:
+        b = np.frombuffer(b"ACGT" * 10 + b"N" + b"CGT" + b"ACGT" * 9, np.uint8)
+        assert b.size == 80 and b[40] == ord("N")
+        o = np.array([0, b.size], np.uint64)
+        kc.add_batch(b, o)
+        t = kc.export()
+        assert t.n_distinct == 1 and t.n_total == 1 and t.equals(oracle.count_lr(b, o))
     # header-only / short records: empty result (G-empty)
     with kmc.KmerCounter(mode=kmc.MODE_LR) as kc:
         b = np.frombuffer(b"ACGT" * 19, np.uint8)  # 76 < 80
