@@ -39,8 +39,12 @@
 #define KMC_MSD_LEAF2 2048    // leaf capacity, two-word keys without weights
 #endif
 #define KMC_MSD_LEAF2W 1024   // leaf capacity, two-word keys with weights
+#ifndef KMC_MSD_THREAD_SORT
 #define KMC_MSD_THREAD_SORT 32  // sub-buckets up to this size are insertion-sorted by one thread
+#endif
+#ifndef KMC_MSD_LEAF_LOGNSB
 #define KMC_MSD_LEAF_LOGNSB 9
+#endif
 #define KMC_MSD_LEAF_NSB (1 << KMC_MSD_LEAF_LOGNSB)   // sub-buckets of a leaf: three or four keys each, so the per-thread insertion sorts
                                 // (a chain of dependent LDS round trips per move) stay a handful of moves long
 
