@@ -1090,8 +1090,9 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                     rc = observe(occ, take, kpt);
                     if (rc) return rc;
                     if (c->recovered) break;  // (the sort path has counted the rest of the batch)
-                    if (c->cfg.algo == KMC_ALGO_AUTO && (c->walk_overflowed || (c->rho_last > 0.5 && (take >= 2048 || done * 2 >= n_tiles)))) {
-                        // (the new-key rate only counts once a launch was large or half the batch is through: the
+                    if (c->cfg.algo == KMC_ALGO_AUTO && (c->walk_overflowed || (c->rho_last > 0.5 && (take >= 512 || done * 2 >= n_tiles)))) {
+                        // (the new-key rate only counts once a launch was large -- 512 tiles, 13 M k-mers: the third launch of the
+                        // ramp used to put another 200 M k-mers into the table before the hand-over -- or half the batch is through: the
                         // first tiles of ANY input are all new)
                         // the memos do not help on this input (both levels overflow, or more than one k-mer in
                         // five is new: per-occurrence table updates are the wrong tool): hand the rest
