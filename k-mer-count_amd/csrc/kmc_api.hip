@@ -592,7 +592,7 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     MSD_ENSURE(c->m_nd, term_cap * sizeof(u32));
     MSD_ENSURE(c->m_base, term_cap * sizeof(u32));
     MSD_ENSURE(c->m_ctl, sizeof(MsdCtl));
-    MSD_ENSURE(c->m_cnt, n * sizeof(u64));
+    MSD_ENSURE(c->m_cnt, n * (weights ? sizeof(u64) : sizeof(u32)));
     MSD_ENSURE(c->m_bsum, (std::max<u64>(n_words, term_cap) / KMC_SCAN_PER_BLOCK + 2) * sizeof(u32));
 #undef MSD_ENSURE
     if (!c->h_ctl) HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, sizeof(MsdCtl)));
@@ -649,7 +649,7 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     }
     hipLaunchKernelGGL(kmc_msd_order_kernel, dim3(grid_for(c, n_term, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_term.p, n_term,
                        (const unsigned long long*)c->m_bitmap.p, (const u32*)c->m_rank.p, (MsdTerm*)c->m_ord.p);
-    u64* t_cnt0 = (u64*)c->m_cnt.p;  // pair staging: counts (keys are staged in the key buffers themselves)
+    void* t_cnt0 = c->m_cnt.p;  // pair staging: counts, 64 bits with weights, 32 without (keys are staged in the key buffers themselves)
 #define MSD_LEAF(KWV, WV, CAPV)                                                                                                             \
     do {                                                                                                                                    \
         static std::atomic<unsigned long long> attr{0};                                                                                     \
@@ -680,10 +680,12 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     run.total = weights ? (u64)c->h_ctl->w_total : (u64)c->h_ctl->n_valid;  // what the run's counts sum to
     run.total_known = true;
     if (!weights && c->h_ctl->n_valid >= (1u << 20)) c->msd_dup_heavy = (u64)c->h_ctl->n_valid >= 4 * std::max<u64>(n_pairs, 1);
-    if (KW == 1) hipLaunchKernelGGL(kmc_msd_gather_kernel<1>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, (const u32*)c->m_nd.p, (const u32*)c->m_base.p,
-                                    (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1], (const u64*)t_cnt0, run.hi, run.lo, run.cnt);
-    else hipLaunchKernelGGL(kmc_msd_gather_kernel<2>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, (const u32*)c->m_nd.p, (const u32*)c->m_base.p,
-                            (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1], (const u64*)t_cnt0, run.hi, run.lo, run.cnt);
+#define MSD_GATHER(KWV, WV)                                                                                                                \
+    hipLaunchKernelGGL((kmc_msd_gather_kernel<KWV, WV>), dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, \
+                       (const u32*)c->m_nd.p, (const u32*)c->m_base.p, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1], (const void*)t_cnt0, run.hi, run.lo, run.cnt)
+    if (KW == 1) { if (weights) MSD_GATHER(1, true); else MSD_GATHER(1, false); }
+    else { if (weights) MSD_GATHER(2, true); else MSD_GATHER(2, false); }
+#undef MSD_GATHER
     if (hipGetLastError() != hipSuccess) { c->run_pool.push_back(run); return fail(c, KMC_ERR_HIP, "msd sort: gather launch failed"); }
     if (out) *out = run;
     else if (n_pairs) c->runs.push_back(run);

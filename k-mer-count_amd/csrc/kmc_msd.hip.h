@@ -27,6 +27,7 @@
 // and are dropped.  Keys may carry a 64-bit weight (an existing count): the run-length then sums
 // weights -- that is how count tables and earlier runs are merged and ordered.
 #pragma once
+#include <type_traits>
 #include "kmc_device.hip.h"
 
 #define KMC_MSD_RANGE 65536   // keys per histogram / scatter workgroup (a histogram row of 1025 counters per range)
@@ -580,7 +581,11 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
                          const u64* __restrict__ hi1, const u64* __restrict__ lo1, const u64* __restrict__ w1,
                          const MsdTerm* __restrict__ term, u32 n_term, int kb,
                          u64* __restrict__ s_hi0, u64* __restrict__ s_lo0, u64* __restrict__ s_hi1, u64* __restrict__ s_lo1,
-                         u64* __restrict__ t_cnt, u32* __restrict__ nd, MsdCtl* __restrict__ ctl) {
+                         void* __restrict__ t_cnt_v, u32* __restrict__ nd, MsdCtl* __restrict__ ctl) {
+    // staged counts: 64 bits with weights; 32 bits without (a count is then at most the leaf's size, or the length
+    // of an all-equal terminal, < 2^32): 4 bytes per key less to write here and to read in the gather
+    typedef typename std::conditional<WEIGHTS, u64, u32>::type CntT;
+    CntT* const t_cnt = reinterpret_cast<CntT*>(t_cnt_v);
     extern __shared__ __align__(16) unsigned char msd_smem[];
     MsdLeafLds<KW, WEIGHTS, CAPV>& L = *reinterpret_cast<MsdLeafLds<KW, WEIGHTS, CAPV>*>(msd_smem);
     const u32 t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -603,7 +608,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             s = L.sx[0][0] + L.sx[1][0] + L.sx[2][0] + L.sx[3][0];
         }
         if (tid == 0) {
-            t_lo[T.begin] = klo[T.begin]; if (KW == 2) t_hi[T.begin] = khi[T.begin]; t_cnt[T.begin] = s; nd[t] = 1;
+            t_lo[T.begin] = klo[T.begin]; if (KW == 2) t_hi[T.begin] = khi[T.begin]; t_cnt[T.begin] = (CntT)s; nd[t] = 1;
             if (WEIGHTS) atomicAdd(&ctl->w_total, (unsigned long long)s);
         }
         return;
@@ -664,7 +669,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             sw = L.sx[0][0] + L.sx[1][0] + L.sx[2][0] + L.sx[3][0];
         }
         if (tid == 0) {
-            t_lo[T.begin] = fl; if (KW == 2) t_hi[T.begin] = fh; t_cnt[T.begin] = sw; nd[t] = n ? 1u : 0u;
+            t_lo[T.begin] = fl; if (KW == 2) t_hi[T.begin] = fh; t_cnt[T.begin] = (CntT)sw; nd[t] = n ? 1u : 0u;
             if (WEIGHTS) atomicAdd(&ctl->w_total, (unsigned long long)sw);
         }
         return;
@@ -780,7 +785,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     // are staged at the end)
     u64* const g_lo = t_lo + T.begin;
     u64* const g_hi = KW == 2 ? t_hi + T.begin : nullptr;
-    u64* const g_w = t_cnt + T.begin;
+    u64* const g_w = WEIGHTS ? reinterpret_cast<u64*>(t_cnt_v) + T.begin : nullptr;
     const u32 nbig = L.nbig;
     for (u32 bi = wv; bi < nbig; bi += 4) {
         const u32 d = L.big[bi];
@@ -980,7 +985,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         if (WEIGHTS) { sum = 0; for (u32 j = i; j < iend; ++j) sum += L.b_w[j]; }
         t_lo[T.begin + r] = L.b_lo[i];
         if (KW == 2) t_hi[T.begin + r] = L.b_hi[i];
-        t_cnt[T.begin + r] = sum;
+        t_cnt[T.begin + r] = (CntT)sum;
         wtot += sum;
     }
     if (tid == 0) nd[t] = n_out;
@@ -991,10 +996,12 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
 }
 
 // dense run: terminal t's nd[t] pairs move from its span of the staging arrays to base[t]
-template <int KW>
+template <int KW, bool WEIGHTS>
 __global__ void kmc_msd_gather_kernel(const MsdTerm* __restrict__ term, u32 n_term, const u32* __restrict__ nd, const u32* __restrict__ base,
                                       const u64* __restrict__ s_hi0, const u64* __restrict__ s_lo0, const u64* __restrict__ s_hi1, const u64* __restrict__ s_lo1,
-                                      const u64* __restrict__ t_cnt, u64* __restrict__ o_hi, u64* __restrict__ o_lo, u64* __restrict__ o_cnt) {
+                                      const void* __restrict__ t_cnt_v, u64* __restrict__ o_hi, u64* __restrict__ o_lo, u64* __restrict__ o_cnt) {
+    typedef typename std::conditional<WEIGHTS, u64, u32>::type CntT;   // (as staged by the leaf kernel)
+    const CntT* const t_cnt = reinterpret_cast<const CntT*>(t_cnt_v);
     // one wave per terminal
     const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, n_waves = (gridDim.x * blockDim.x) >> 6;
     for (u32 t = wave; t < n_term; t += n_waves) {
@@ -1004,7 +1011,7 @@ __global__ void kmc_msd_gather_kernel(const MsdTerm* __restrict__ term, u32 n_te
         for (u32 i = lane; i < m; i += 64) {
             o_lo[dst + i] = t_lo[src + i];
             if (KW == 2) o_hi[dst + i] = t_hi[src + i];
-            o_cnt[dst + i] = t_cnt[src + i];
+            o_cnt[dst + i] = (u64)t_cnt[src + i];
         }
     }
 }
