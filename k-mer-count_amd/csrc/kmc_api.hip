@@ -816,6 +816,29 @@ int recover_overflow(kmc_ctx* c) {
     return run_sort_path(c, r.d_bases, r.d_offsets, r.n_reads, r.n_bases, from);
 }
 
+// AUTO hands a batch to the sort path after a launch or two of the walk kernel.  When the table held nothing at
+// the start of the batch, what those launches put into it is dropped and the WHOLE batch is sorted: the table
+// stays empty, so kmc_finalize has a single run to show (zero copy) instead of merging 14 M table entries with
+// a 745 M-entry run by one more sort of everything (first step on 1 GB of random 63-mers: 100 ms of kernels
+// and 60 GB of buffers less).  ctr0 = the device counters at the start of the batch.
+int drop_batch_from_table(kmc_ctx* c, const u64* ctr0) {
+    GTable g = gtable_of(c, c->tab);
+    const int grid = grid_for(c, c->tab.cap, 256);
+    if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g);
+    else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(c->d_counters, ctr0, KMC_CTR_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    { int rs = sk_clear(c); if (rs) return rs; }
+    c->sk_dirty = false;
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // (ctr0 is the caller's stack memory)
+    memcpy(c->h_counters, ctr0, KMC_CTR_N * sizeof(u64));
+    c->direct_seen = ctr0[KMC_CTR_BADBASE];
+    c->kmers_seen = ctr0[KMC_CTR_KMERS];
+    c->risky.armed = false;
+    c->fin_parity = 0;
+    return KMC_OK;
+}
+
 // pieces of at most KMC_WALK_MAX_READ bases for a batch with longer reads (kmc_walk.hip.h): vr_reads = [starts | ends]
 int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
     // pieces per read (u32), their exclusive prefix (the three-kernel scan of kmc_msd.hip.h), then the pieces
@@ -856,6 +879,10 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     { int rc = settle_sk_polled(c); if (rc) return rc; }
     c->recovered = false;
     c->sorted_valid = false;
+    // (for drop_batch_from_table: did this batch start on an empty table?  The counters are as of a poll.)
+    const bool batch_on_empty_table = !c->pending && c->h_counters[KMC_CTR_OCCUPIED] == 0 && c->h_counters[KMC_CTR_SPILL] == 0;
+    u64 ctr0[KMC_CTR_N];
+    memcpy(ctr0, c->h_counters, sizeof(ctr0));
     c->st.n_reads += n_reads;
     c->st.n_bases += n_bases;
     c->st.n_batches += 1;
@@ -1101,8 +1128,13 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                         // of the batch to the sort path
                         // ... from the end of the last piece walked: the windows ENDING before it are counted
                         u64 pos = 0;
-                        HIPCHK(c, hipMemcpyAsync(&pos, d_ve + (done * 64 - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-                        HIPCHK(c, hipStreamSynchronize(c->stream));
+                        if (batch_on_empty_table) {
+                            rc = drop_batch_from_table(c, ctr0);   // (the whole batch goes to the sort path)
+                            if (rc) return rc;
+                        } else {
+                            HIPCHK(c, hipMemcpyAsync(&pos, d_ve + (done * 64 - 1), sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+                            HIPCHK(c, hipStreamSynchronize(c->stream));
+                        }
                         stream_from = pos;
                         run_sort = true;
                         c->prefer_sort = true;
