@@ -77,6 +77,12 @@ struct kmc_ctx {
     bool walk_ws_clean = false;  // workspace header + dense counters are zero (left so by kmc_walk_tail_kernel)
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
     DevBuf s_lo[2], s_hi[2];
+    // KMC_ALGO_SORT accumulates: a batch only EXTRACTS its keys behind those of the batches before it (s_lo[0] /
+    // s_hi[0]); they are sorted into ONE run when somebody needs the result (kmc_finalize, a reduce) or when 2^31
+    // positions have come together.  (Sorting batch by batch left one run per batch -- 16 for a 1 GB file read in
+    // 64 MB chunks -- and kmc_finalize then merged them by sorting everything once more: 0.9 s for 760 M 63-mers.)
+    u64 acc_n = 0;           // key positions accumulated and not yet sorted
+    u64 acc_hint = 0;        // positions the caller expects in all (kmc_count_file: the file size); sizes the first allocation
     DevBuf lr_rank;  // LR mode: rank of every position's 27-mer among the batch's distinct 27-mers
     // hand-written MSD radix sort (kmc_msd.hip.h): per-range histograms, segment lists, terminals
     DevBuf m_hist, m_stot, m_bsum, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_cnt, m_w[2];
@@ -162,6 +168,23 @@ int ensure(kmc_ctx* c, DevBuf& b, size_t bytes) {
     return KMC_OK;
 }
 
+// like ensure, but the first `keep` bytes survive (grows geometrically: the copy is amortised)
+int ensure_keep(kmc_ctx* c, DevBuf& b, size_t bytes, size_t keep) {
+    if (b.bytes >= bytes && b.p) return KMC_OK;
+    if (!b.p || !keep) return ensure(c, b, bytes);
+    const size_t want = std::max(bytes + bytes / 8 + 256, b.bytes * 2);
+    void* np = nullptr;
+    HIPCHK(c, hipMalloc(&np, want));
+    if (hipMemcpyAsync(np, b.p, keep, hipMemcpyDeviceToDevice, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+        (void)hipFree(np);
+        return fail(c, KMC_ERR_HIP, "growing the key accumulator failed");
+    }
+    (void)hipFree(b.p);
+    b.p = np;
+    b.bytes = want;
+    return KMC_OK;
+}
+
 void free_buf(DevBuf& b) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
@@ -197,6 +220,7 @@ int alloc_table(kmc_ctx* c, Table& t, u64 cap) {
 
 // drop the live runs; their buffers go back to the pool (release == true: really free everything)
 void free_runs(kmc_ctx* c, bool release = false) {
+    c->acc_n = 0;  // (keys extracted and not yet sorted go with the runs)
     for (auto& r : c->runs) { r.n = 0; c->run_pool.push_back(r); }
     c->runs.clear();
     if (c->view_run.lo) { c->view_run.n = 0; c->run_pool.push_back(c->view_run); c->view_run = kmc_ctx::Run{}; }
@@ -695,29 +719,50 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
 
 // Count the windows ending in [range_begin, n_bases) by extract -> sort -> run-length, in sub-batches
 // of at most 2^31 base positions (2 x 16-32 GiB of keys in flight).  Each sub-batch leaves one run.
+// Sort what the batches since the last flush have extracted: one run.
+int flush_acc(kmc_ctx* c) {
+    if (!c->acc_n) return KMC_OK;
+    const u64 n = c->acc_n;
+    int rc = ensure(c, c->s_lo[1], (size_t)n * sizeof(u64));
+    if (rc) return rc;
+    if (c->KW == 2) { rc = ensure(c, c->s_hi[1], (size_t)n * sizeof(u64)); if (rc) return rc; }
+    rc = launch_begin(c);  // (the event pair brackets the whole sort: levels, leaves, gather)
+    if (rc) return rc;
+    u64* const khi[2] = {(u64*)c->s_hi[0].p, (u64*)c->s_hi[1].p};
+    u64* const klo[2] = {(u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p};
+    u64* const kwt[2] = {nullptr, nullptr};
+    c->acc_n = 0;  // (whatever happens below, these keys are not sorted twice)
+    rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen, c->KW);
+    if (rc) return rc;
+    rc = launch_end(c);
+    if (rc) return rc;
+    c->pending = true;
+    return KMC_OK;
+}
+
 int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 range_begin) {
     const u64 n_chunks = (n_bases + KMC_CHUNK - 1) / KMC_CHUNK;
-    const u64 SB = 1ull << 21;  // chunks per sub-batch (2^31 positions: the run kernels index with u32)
+    const u64 SB = 1ull << 21;  // chunks per sort (2^31 positions: the run kernels index with u32)
     for (u64 cb = range_begin / KMC_CHUNK; cb < n_chunks; cb += SB) {
         const u64 ce = std::min(n_chunks, cb + SB);
         const u64 n = (ce - cb) * KMC_CHUNK;
-        for (int i = 0; i < 2; ++i) {
-            int rc = ensure(c, c->s_lo[i], (size_t)n * sizeof(u64));
+        if (c->acc_n + n > SB * KMC_CHUNK) { int rc = flush_acc(c); if (rc) return rc; }
+        // room behind the keys already there (sized by the caller's hint the first time)
+        const u64 want = std::max<u64>(c->acc_n + n, std::min<u64>(c->acc_hint, SB * KMC_CHUNK));
+        int rc = ensure_keep(c, c->s_lo[0], (size_t)(c->s_lo[0].bytes >= (c->acc_n + n) * sizeof(u64) ? (c->acc_n + n) : want) * sizeof(u64), (size_t)c->acc_n * sizeof(u64));
+        if (rc) return rc;
+        if (c->KW == 2) {
+            rc = ensure_keep(c, c->s_hi[0], (size_t)(c->s_hi[0].bytes >= (c->acc_n + n) * sizeof(u64) ? (c->acc_n + n) : want) * sizeof(u64), (size_t)c->acc_n * sizeof(u64));
             if (rc) return rc;
-            if (c->KW == 2) { rc = ensure(c, c->s_hi[i], (size_t)n * sizeof(u64)); if (rc) return rc; }
         }
-        // (the event pair brackets the whole pipeline of the sub-batch: extraction, sort levels, leaves, gather)
-        int rc = launch_begin(c);
+        rc = launch_begin(c);  // (this event pair brackets the extraction; the sort has its own at the flush)
         if (rc) return rc;
-        rc = launch_extract(c, d_bases, d_offsets, n_reads, n_bases, cb, ce, range_begin, (u64*)c->s_hi[0].p, (u64*)c->s_lo[0].p);
-        if (rc) return rc;
-        u64* const khi[2] = {(u64*)c->s_hi[0].p, (u64*)c->s_hi[1].p};
-        u64* const klo[2] = {(u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p};
-        u64* const kwt[2] = {nullptr, nullptr};
-        rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen, c->KW);
+        rc = launch_extract(c, d_bases, d_offsets, n_reads, n_bases, cb, ce, range_begin,
+                            c->KW == 2 ? (u64*)c->s_hi[0].p + c->acc_n : nullptr, (u64*)c->s_lo[0].p + c->acc_n);
         if (rc) return rc;
         rc = launch_end(c);
         if (rc) return rc;
+        c->acc_n += n;
     }
     c->pending = true;
     return KMC_OK;
@@ -1405,6 +1450,8 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     int rc;
     bool tried_fast = false;
     int fgrid_used = 0;
+    rc = flush_acc(c);  // keys the sort path has extracted since the last flush: one run
+    if (rc) return rc;
     if (c->runs.empty()) {
         // speculative small-table finalize, queued behind whatever is still running
         const size_t fb = (size_t)KMC_OCC_LIST_CAP * sizeof(u64);
@@ -1422,6 +1469,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         tried_fast = true;
     }
     rc = poll_and_settle(c);
+    if (!rc && c->acc_n) rc = flush_acc(c);  // (the poll may have recovered an overflow by extracting the rest of a batch)
     if (rc) return rc;
     if (c->sk_dirty) {
         // the last batch's walk launches may have left counts in the (k+16)-mer table: the poll tells
@@ -1437,6 +1485,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
                 HIPCHK(c, hipGetLastError());
             }
             rc = poll_and_settle(c);
+    if (!rc && c->acc_n) rc = flush_acc(c);  // (the poll may have recovered an overflow by extracting the rest of a batch)
             if (rc) return rc;
         }
     }
@@ -1450,6 +1499,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
         HIPCHK(c, hipGetLastError());
         rc = poll_and_settle(c);
+    if (!rc && c->acc_n) rc = flush_acc(c);  // (the poll may have recovered an overflow by extracting the rest of a batch)
         if (rc) return rc;
     }
     const bool fast_done = tried_fast && c->h_counters[KMC_CTR_FASTFIN] == 1 && c->runs.empty();  // (the poll may have recovered an overflow: runs exist now)
@@ -1611,7 +1661,7 @@ static int kmc_pack_slab_device_impl(kmc_ctx* c, void* d_slab, uint64_t slab_ent
     if (!c->sorted_valid) {
         // not finalized: pack the live table (unsorted) -- the device decides whether it fits
         GTable g = gtable_of(c, c->tab);
-        const int force = c->runs.empty() ? 0 : 1;  // sorted runs exist only for high-cardinality input: far too large
+        const int force = (c->runs.empty() && !c->acc_n) ? 0 : 1;  // sorted runs / extracted keys exist only for high-cardinality input: far too large
         const int grid = grid_for(c, std::min<u64>(slab_entries, KMC_OCC_LIST_CAP), 256);
         if (c->KW == 1) hipLaunchKernelGGL(kmc_pack_slab_live_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64)slab_entries, force, (u64*)d_slab);
         else hipLaunchKernelGGL(kmc_pack_slab_live_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64)slab_entries, force, (u64*)d_slab);
@@ -1669,7 +1719,7 @@ static int kmc_poll_impl(kmc_ctx* c) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     int rc = poll_and_settle(c);
     if (rc) return rc;
-    if (c->runs.empty()) c->st.n_kmers = c->h_counters[KMC_CTR_KMERS];  // (the sort path counts at finalize)
+    if (c->runs.empty() && !c->acc_n) c->st.n_kmers = c->h_counters[KMC_CTR_KMERS];  // (the sort path counts at finalize)
     harvest_timing(c);
     return KMC_OK;
 }
@@ -1731,12 +1781,15 @@ static int count_file_pipeline(kmc_ctx** ctxs, uint32_t n_ctx, const char* path,
     // buffers take longer to allocate and the first upload starts later); KMC_INGEST_CHUNK_BYTES overrides
     u64 chunk_bytes = 0;
     if (const char* e = getenv("KMC_INGEST_CHUNK_BYTES")) { u64 v = strtoull(e, nullptr, 10); if (v) chunk_bytes = v; }
-    if (!chunk_bytes) {
+    u64 fsize = 0;
+    {
         FILE* f = fopen(path, "rb");
-        u64 fsize = 0;
         if (f) { if (fseeko(f, 0, SEEK_END) == 0) fsize = (u64)ftello(f); fclose(f); }
-        chunk_bytes = std::min<u64>(std::max<u64>(fsize / 16, 32ull << 20), 128ull << 20);
     }
+    if (!chunk_bytes) chunk_bytes = std::min<u64>(std::max<u64>(fsize / 16, 32ull << 20), 128ull << 20);
+    // should the input turn out high-cardinality, the sort path's key accumulator is allocated once for the
+    // file's share of this ctx (a base position per byte of text at most) instead of growing chunk by chunk
+    for (uint32_t i = 0; i < n_ctx; ++i) ctxs[i]->acc_hint = fsize / n_ctx + chunk_bytes;
     KmcFastaIngest ing;
     std::string err;
     int rc = ing.open(path, chunk_bytes, &err);
