@@ -923,6 +923,47 @@ def test_msd_sort_path_matches_oracle(kmc, oracle, k, pool, n_rec):
         assert kc.export().equals(oracle.count_kmers(hb, ho, k, True, method=1))
 
 
+@pytest.mark.parametrize("k", [31, 63])
+def test_sort_path_accumulates_batches(kmc, oracle, k, tmp_path):
+    """KMC_ALGO_SORT only extracts a batch's keys behind those of the batches before it and sorts when the result is
+    needed: batches of growing size (the accumulator is re-allocated with its contents kept), a finalize in the
+    middle (one run so far), more batches (a second run, merged at the next finalize), reset (extracted keys are
+    dropped with the runs) -- always the oracle's table of everything added since the last reset.  And a file
+    read in many chunks (kmc_count_file sizes the accumulator from the file size) gives the whole file's table."""
+    import subprocess
+    from conftest import ROOT
+    s = kmc.Synth(seed=77, pool=0)
+    hb, ho = kmc.synth_reads_host(s, 0, 9000)
+    cuts = [0, 500, 1500, 4000, 9000]
+    def part(a, b):
+        return hb[a * 400:b * 400], ho[a:b + 1] - ho[a]
+    with kmc.KmerCounter(k=k, algo=kmc.ALGO_SORT) as kc:
+        for a, b in zip(cuts[:3], cuts[1:3]):
+            kc.add_batch(*part(a, b))
+        assert kc.export().equals(oracle.count_kmers(*part(0, cuts[2]), k, True, method=1))          # finalize in the middle
+        for a, b in zip(cuts[2:], cuts[3:]):
+            kc.add_batch(*part(a, b))
+        assert kc.export().equals(oracle.count_kmers(hb, ho, k, True, method=1))                     # run + new keys
+        kc.reset()
+        kc.add_batch(*part(0, 500))
+        kc.reset()                                                                                   # extracted, never sorted: dropped
+        kc.add_batch(*part(500, 1500))
+        assert kc.export().equals(oracle.count_kmers(*part(500, 1500), k, True, method=1))
+    p = tmp_path / "rnd.fasta"
+    with open(p, "wb") as f:
+        subprocess.run([os.path.join(ROOT, "bin", "kmc-genfasta"), "--bytes", "6000000", "--seed", "9", "--pool", "0"], stdout=f, check=True)
+    fb, fo = oracle.parse_fasta(str(p))
+    want = oracle.count_kmers(fb, fo, k, True, method=1)
+    os.environ["KMC_INGEST_CHUNK_BYTES"] = "400000"
+    try:
+        with kmc.KmerCounter(k=k) as kc:
+            nd, nt = kc.count_file(str(p))
+            assert (nd, nt) == (want.n_distinct, want.n_total) and kc.export().equals(want)
+            assert kc.stats().n_batches >= 10
+    finally:
+        del os.environ["KMC_INGEST_CHUNK_BYTES"]
+
+
 def test_two_word_sort_with_both_leaf_sizes(kmc, oracle):
     """Two-word keys are sorted with leaves of 2048 keys -- until a sort of the ctx has collapsed its keys more
     than fourfold (heavily repeated keys: the smaller leaves are faster there), after which it uses leaves of
