@@ -392,8 +392,9 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                     // (SINK == 1) the wave's 1024 keys of this chunk start at the position of lane 0's first key
                     u64* const o_lo = SINK == 1 ? out_lo + (pp - 16ull * (u64)lane - chunk_begin * KMC_CHUNK) : nullptr;
                     u64* const o_hi = (SINK == 1 && KW == 2) ? out_hi + (pp - 16ull * (u64)lane - chunk_begin * KMC_CHUNK) : nullptr;
-                    // (two-word keys keep the direct stores: 32 more registers for the second word spill, 7.5 -> 9.1 ms)
-                    u64 vlo[(SINK == 1 && KW == 1) ? 16 : 1];
+                    // (two-word keys: the low words leave transposed, the high words by direct stores -- both words in
+                    //  registers, 64 of them, made the kernel slower: 7.5 -> 9.1 ms)
+                    u64 vlo[SINK == 1 ? 16 : 1];
                     u32 missmask = 0;  // bit j: this lane's window j missed both home slots
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
@@ -416,12 +417,12 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         if constexpr (SINK == 0) {
                             missmask |= stream_probe<KW>(L, khi, klo, ok) ? (1u << j) : 0u;
                         } else {
-                            if constexpr (KW == 1) vlo[j] = ok ? klo : ~0ull;
-                            else { o_lo[16 * lane + j] = ok ? klo : ~0ull; o_hi[16 * lane + j] = ok ? khi : ~0ull; }
+                            vlo[j] = ok ? klo : ~0ull;
+                            if constexpr (KW == 2) o_hi[16 * lane + j] = ok ? khi : ~0ull;
                             nk += ok;
                         }
                     }
-                    if constexpr (SINK == 1 && KW == 1) stream_store_transposed(L.tr[wv], lane, vlo, o_lo);
+                    if constexpr (SINK == 1) stream_store_transposed(L.tr[wv], lane, vlo, o_lo);
                     if constexpr (SINK == 0) {
                         nk += (u32)__popc(~inv16 & 0xFFFFu);
                         // the chunk's misses (first sight of a key, keys that did not fit their home bucket):
