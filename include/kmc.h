@@ -62,8 +62,9 @@ typedef enum kmc_mode {
 typedef enum kmc_algo {
     KMC_ALGO_AUTO = 0,   /* pick per batch: WALK for short reads, SORT once the input proves high-cardinality, else STREAM */
     KMC_ALGO_STREAM = 1, /* per-k-mer LDS partial histogram + global atomics (any input) */
-    KMC_ALGO_WALK = 2,   /* memoised successor walk: one LDS lookup per 16 bases (reads <= 416 bases) */
-    KMC_ALGO_SORT = 3    /* extract every window, device radix sort, run-length (high-cardinality input) */
+    KMC_ALGO_WALK = 2,   /* memoised successor walk: one LDS lookup per 16 bases (longer reads as overlapping pieces of 416) */
+    KMC_ALGO_SORT = 3    /* extract every window; batches accumulate; hand-written MSD radix sort + run-length when the
+                            result is needed (high-cardinality input) */
 } kmc_algo;
 
 /* Deviations from the config sketched in SURVEY.md 8b (`n_devices`, `device_ids*`, `backend`), on purpose:
