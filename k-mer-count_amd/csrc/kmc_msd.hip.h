@@ -561,7 +561,8 @@ template <int KW, bool WEIGHTS, int CAPV> struct MsdLeafLds {
     u64 b_hi[KW == 2 ? CAP : 1];
     u64 b_w[WEIGHTS ? CAP : 1];   // weights (counts) of the keys
     // a wave's scratch for a large sub-bucket (8 KB per workgroup in all; larger sub-buckets use the global scratch)
-    static constexpr int SCR = (KW == 1 && !WEIGHTS) ? 256 : ((KW == 2 && WEIGHTS) ? 64 : ((KW == 2 && CAPV > 1024) ? 192 : 128));  // (128 for one-word keys: no faster on random keys, LR leaves 0.41 -> 0.65 ms)
+    static constexpr int SCR = (KW == 1 && !WEIGHTS) ? 256 : ((KW == 2 && WEIGHTS) ? 64 : ((KW == 2 && CAPV > 1024) ? 16 : 128));  // (128 for one-word keys: no faster on random keys, LR leaves 0.41 -> 0.65 ms; two-word leaves of 2048 keys: 16, which
+                                                                                                                      //  makes it four leaves per CU -- they sort random keys, the repetitive ones go to leaves of 1024)
     u64 s_lo[4][SCR];
     u64 s_hi[KW == 2 ? 4 : 1][KW == 2 ? SCR : 1];
     u64 s_w[WEIGHTS ? 4 : 1][WEIGHTS ? SCR : 1];
