@@ -584,7 +584,7 @@ int launch_extract(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64
 // of segments that go on) and one for the size of the run.
 // KW: words per key (1: lo only).  out == nullptr: the run joins c->runs; otherwise it is handed to the
 // caller (n == 0 when nothing but filler came in).
-int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w[2], u64 n, unsigned kb, int KW, kmc_ctx::Run* out = nullptr) {
+int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w[2], u64 n, unsigned kb, int KW, kmc_ctx::Run* out = nullptr, bool repeated_keys = false) {
     if (out) *out = kmc_ctx::Run{};
     if (!n) return KMC_OK;
     if (n >= (1ull << 32) - KMC_MSD_RANGE) return fail(c, KMC_ERR_ARG, "msd sort: more than 2^32 keys in one pass");
@@ -594,6 +594,7 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     // a ctx whose last sort collapsed its keys more than fourfold keeps the smaller leaves
     u32 leaf_cap = KW == 1 ? KMC_MSD_LEAF1 : (w[0] ? KMC_MSD_LEAF2W : KMC_MSD_LEAF2);
     if (KW == 2 && !w[0] && c->msd_dup_heavy) leaf_cap = 1024;
+    const bool clustered = repeated_keys || c->msd_dup_heavy;   // (one-word leaves: the larger wave scratch)
     const u64 max_seg = n / leaf_cap + 257;
     const u64 max_ranges = n / KMC_MSD_RANGE + max_seg + 1;
     const u64 term_cap = 16 * (n / leaf_cap) + 65536;
@@ -674,18 +675,22 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     hipLaunchKernelGGL(kmc_msd_order_kernel, dim3(grid_for(c, n_term, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_term.p, n_term,
                        (const unsigned long long*)c->m_bitmap.p, (const u32*)c->m_rank.p, (MsdTerm*)c->m_ord.p);
     void* t_cnt0 = c->m_cnt.p;  // pair staging: counts, 64 bits with weights, 32 without (keys are staged in the key buffers themselves)
-#define MSD_LEAF(KWV, WV, CAPV)                                                                                                             \
+#define MSD_LEAF(KWV, WV, CAPV, SCRV)                                                                                                       \
     do {                                                                                                                                    \
         static std::atomic<unsigned long long> attr{0};                                                                                     \
-        if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_msd_leaf_kernel<KWV, WV, CAPV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdLeafLds<KWV, WV, CAPV>)); \
-        hipLaunchKernelGGL((kmc_msd_leaf_kernel<KWV, WV, CAPV>), dim3(n_term), dim3(KMC_MSD_THREADS), sizeof(MsdLeafLds<KWV, WV, CAPV>), c->stream,   \
+        if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_msd_leaf_kernel<KWV, WV, CAPV, SCRV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdLeafLds<KWV, WV, CAPV, SCRV>)); \
+        hipLaunchKernelGGL((kmc_msd_leaf_kernel<KWV, WV, CAPV, SCRV>), dim3(n_term), dim3(KMC_MSD_THREADS), sizeof(MsdLeafLds<KWV, WV, CAPV, SCRV>), c->stream, \
                            (const u64*)hi[0], (const u64*)lo[0], (const u64*)(weights ? w[0] : nullptr), (const u64*)hi[1], (const u64*)lo[1], (const u64*)(weights ? w[1] : nullptr), \
                            (const MsdTerm*)c->m_ord.p, n_term, (int)kb, hi[0], lo[0], hi[1], lo[1], t_cnt0, (u32*)c->m_nd.p, ctl); \
     } while (0)
-    if (KW == 1) { if (weights) MSD_LEAF(1, true, KMC_MSD_LEAF1); else MSD_LEAF(1, false, KMC_MSD_LEAF1); }
-    else if (weights) MSD_LEAF(2, true, KMC_MSD_LEAF2W);
-    else if (leaf_cap > 1024) MSD_LEAF(2, false, KMC_MSD_LEAF2);
-    else MSD_LEAF(2, false, 1024);
+    // (leaf size and wave scratch by what the keys look like: kmc_msd.hip.h, MsdLeafLds)
+    if (KW == 1) {
+        if (weights) MSD_LEAF(1, true, KMC_MSD_LEAF1, 128);
+        else if (clustered) MSD_LEAF(1, false, KMC_MSD_LEAF1, 256);
+        else MSD_LEAF(1, false, KMC_MSD_LEAF1, 2);   // (23,004 bytes of LDS: seven leaves per CU at 512-byte granules)
+    } else if (weights) MSD_LEAF(2, true, KMC_MSD_LEAF2W, 64);
+    else if (leaf_cap > 1024) MSD_LEAF(2, false, KMC_MSD_LEAF2, 16);
+    else MSD_LEAF(2, false, 1024, 128);
 #undef MSD_LEAF
     {   // base[t] = exclusive prefix of the terminals' pair counts
         const u32 nb = (n_term + KMC_SCAN_PER_BLOCK - 1) / KMC_SCAN_PER_BLOCK;
@@ -1040,7 +1045,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                                    d_bases, n_bases, q0, q1, klo[0], (const u64*)nullptr, 0u, (u32*)nullptr);
                 HIPCHK(c, hipGetLastError());
                 kmc_ctx::Run mers;
-                rc = msd_sort_to_run(c, khi, klo, kwt, nq, 2u * KMC_LR_L, 1, &mers);
+                rc = msd_sort_to_run(c, khi, klo, kwt, nq, 2u * KMC_LR_L, 1, &mers, true);
                 if (rc) return rc;
                 const u64 n_distinct = mers.n;
                 if (n_distinct) {  // 2. every position's rank in it
@@ -1056,7 +1061,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                                        d_offsets, n_reads, p0, p1, q0, nq, (const u32*)c->lr_rank.p, B, klo[0], c->d_counters);
                     HIPCHK(c, hipGetLastError());
                     kmc_ctx::Run run;
-                    rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)B, 1, &run);
+                    rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)B, 1, &run, true);
                     if (rc) { c->run_pool.push_back(mers); return rc; }
                     if (run.n) {
                         hipLaunchKernelGGL(kmc_lr_compose_kernel, dim3(grid_for(c, run.n, 256)), dim3(256), 0, c->stream, run.hi, run.lo, run.n, (const u64*)mers.lo, B);

@@ -551,7 +551,7 @@ __global__ void kmc_msd_order_kernel(const MsdTerm* __restrict__ term, u32 n_ter
 // One workgroup per terminal (in position order).  Result: the terminal's (key, count) pairs, sorted,
 // written at the terminal's own positions of the OTHER key buffer (dead there) and of t_cnt, and
 // nd[t] = their number.  kmc_msd_gather_kernel then makes the run dense.
-template <int KW, bool WEIGHTS, int CAPV> struct MsdLeafLds {
+template <int KW, bool WEIGHTS, int CAPV, int SCRV> struct MsdLeafLds {
     static constexpr int CAP = CAPV;   // leaf capacity (KMC_MSD_LEAF1 / LEAF2 / LEAF2W; two-word sorts also run with 1024)
     // ONE image of the leaf (the keys come in through registers: with a second image a one-word leaf took
     // 36 KB and four leaves fit a CU; now five do).  A large sub-bucket is split through a small per-wave
@@ -561,14 +561,17 @@ template <int KW, bool WEIGHTS, int CAPV> struct MsdLeafLds {
     u64 b_hi[KW == 2 ? CAP : 1];
     u64 b_w[WEIGHTS ? CAP : 1];   // weights (counts) of the keys
     // a wave's scratch for a large sub-bucket (8 KB per workgroup in all; larger sub-buckets use the global scratch)
-    static constexpr int SCR = (KW == 1 && !WEIGHTS) ? 256 : ((KW == 2 && WEIGHTS) ? 64 : ((KW == 2 && CAPV > 1024) ? 16 : 128));  // (128 for one-word keys: no faster on random keys, LR leaves 0.41 -> 0.65 ms; two-word leaves of 2048 keys: 16, which
-                                                                                                                      //  makes it four leaves per CU -- they sort random keys, the repetitive ones go to leaves of 1024)
+    // SCRV keys of scratch per wave.  Random keys almost never need it (sub-buckets of more than 32 keys), repeated and
+    // clustered keys do all the time; it decides how many leaves fit a CU: one-word keys 8 -> seven leaves (8.4 -> 6.6 ms
+    // on 831 M random keys), 256 -> five (LR leaves 0.41 ms; through the global scratch 2.2 ms); two-word leaves of
+    // 2048 keys 16 -> four.  The host picks by what the ctx's last sort looked like (kmc_api.hip: msd_dup_heavy).
+    static constexpr int SCR = SCRV;
     u64 s_lo[4][SCR];
     u64 s_hi[KW == 2 ? 4 : 1][KW == 2 ? SCR : 1];
     u64 s_w[WEIGHTS ? 4 : 1][WEIGHTS ? SCR : 1];
     u32 cnt[KMC_MSD_LEAF_NSB], off[KMC_MSD_LEAF_NSB + 1];   // (later: the run heads' positions, 16 bits each)
-    u32 big[KMC_MSD_LEAF1 / KMC_MSD_THREAD_SORT + 4];     // sub-buckets too large for one thread
-    u32 woff[4][132];                                     // a wave's own offsets when it splits such a sub-bucket again (its counters: cnt)
+    u32 big[CAPV / (KMC_MSD_THREAD_SORT + 1) + 2];        // sub-buckets too large for one thread (more than THREAD_SORT keys each)
+    u32 woff[4][129];                                     // a wave's own offsets when it splits such a sub-bucket again (its counters: cnt)
     u32 nbig;
     u32 wsum[4];
     u32 bad;                  // a sub-bucket was too large for the in-wave rank sort
@@ -576,7 +579,7 @@ template <int KW, bool WEIGHTS, int CAPV> struct MsdLeafLds {
     u64 sx[4][2], sy[4][2];
 };
 
-template <int KW, bool WEIGHTS, int CAPV>
+template <int KW, bool WEIGHTS, int CAPV, int SCRV>
 __global__ __launch_bounds__(KMC_MSD_THREADS)
 void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo0, const u64* __restrict__ w0,
                          const u64* __restrict__ hi1, const u64* __restrict__ lo1, const u64* __restrict__ w1,
@@ -588,7 +591,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     typedef typename std::conditional<WEIGHTS, u64, u32>::type CntT;
     CntT* const t_cnt = reinterpret_cast<CntT*>(t_cnt_v);
     extern __shared__ __align__(16) unsigned char msd_smem[];
-    MsdLeafLds<KW, WEIGHTS, CAPV>& L = *reinterpret_cast<MsdLeafLds<KW, WEIGHTS, CAPV>*>(msd_smem);
+    MsdLeafLds<KW, WEIGHTS, CAPV, SCRV>& L = *reinterpret_cast<MsdLeafLds<KW, WEIGHTS, CAPV, SCRV>*>(msd_smem);
     const u32 t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const MsdTerm T = term[t];
     const u64* khi = T.parity ? hi1 : hi0;
@@ -619,7 +622,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     //    actual key range.  (A leaf may hold several children of its parent; the first version took the 8
     //    bits below the highest DIFFERING bit -- for a leaf that straddles a power of two, e.g. children
     //    0111111111 and 1000000000, that put all keys into two sub-buckets: 65 of the sort's 97 ms.)
-    constexpr int PER = MsdLeafLds<KW, WEIGHTS, CAPV>::CAP / KMC_MSD_THREADS;  // keys per thread, in registers
+    constexpr int PER = MsdLeafLds<KW, WEIGHTS, CAPV, SCRV>::CAP / KMC_MSD_THREADS;  // keys per thread, in registers
     u64 rlo[PER], rhi[KW == 2 ? PER : 1], rw[WEIGHTS ? PER : 1];
     u64 mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
 #pragma unroll
@@ -819,7 +822,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         };
         // scratch of this sub-bucket: the wave's LDS scratch (indexed 0 .. m) or global memory (indexed like b: o .. o + m);
         // xo is what turns a b index into a scratch index
-        constexpr u32 SCR = (u32)MsdLeafLds<KW, WEIGHTS, CAPV>::SCR;
+        constexpr u32 SCR = (u32)MsdLeafLds<KW, WEIGHTS, CAPV, SCRV>::SCR;
         const bool use_g = m > SCR;
         const u32 xo = use_g ? 0u : o;
         u64* const x_lo = use_g ? g_lo : &L.s_lo[wv][0];
@@ -949,7 +952,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     //    (16 bits each, in the space of the sub-bucket counters and offsets, dead by now); phase 2: one thread per run -- its length is the distance
     //    to the next head (the first version let the head's thread walk its run: one thread, thousands of
     //    dependent LDS reads for a key with thousands of copies, everybody else waiting at the barrier).
-    static_assert(sizeof(L.cnt) + sizeof(L.off) >= MsdLeafLds<KW, WEIGHTS, CAPV>::CAP * sizeof(unsigned short), "run-head list does not fit");
+    static_assert(sizeof(L.cnt) + sizeof(L.off) >= MsdLeafLds<KW, WEIGHTS, CAPV, SCRV>::CAP * sizeof(unsigned short), "run-head list does not fit");
     unsigned short* const hidx = reinterpret_cast<unsigned short*>(L.cnt);
     for (u32 c0 = 0; c0 < n; c0 += KMC_MSD_THREADS * 4) {
         const u32 i0 = c0 + tid * 4;  // each thread owns 4 consecutive elements of this slab
