@@ -264,14 +264,7 @@ __device__ __forceinline__ u32 walk_node(WalkLds<KW>& L, WCtx nk) {
 // the (k+16)-mer of a step: context (2k bits, public code, newest base lowest) followed by the label
 // (16 bases, internal code, first base in the low bits)
 // count one traversal of the step (ctx, label) in the (k+16)-mer table
-#ifdef KMC_SK_ADD_NOINLINE
-__device__ __noinline__ void sk_add(const GTable& sk, WCtx ctx, u32 label) {
-#else
 __device__ __forceinline__ void sk_add(const GTable& sk, WCtx ctx, u32 label) {
-#endif
-#ifdef KMC_WALK_NO_SK
-    return;
-#endif
     const u32 pub = label ^ ((label >> 1) & 0x55555555u);  // A0 C1 T2 G3 -> A0 C1 G2 T3
     const u32 be = le_to_be(pub);                           // first base of the step in the top bits
     const u64 lo = (ctx.lo << 32) | be;
@@ -462,11 +455,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     extern __shared__ __align__(16) unsigned char walk_smem[];
     WalkLds<KW>& L = *reinterpret_cast<WalkLds<KW>*>(walk_smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-#ifdef KMC_WALK_ONE_COUNTER
-    const u32 cpar = 0u;
-#else
     const u32 cpar = (u32)lane & 1u;  // which of the two traversal counters of a node / edge this lane uses
-#endif
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
