@@ -926,7 +926,17 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
     // the previous batch's (k+16)-mer counts, if it left any: the counters are as of a poll that came after
     // its last launch (every launch sets `pending`), so an empty table is known to be empty
-    { int rc = settle_sk_polled(c); if (rc) return rc; }
+    {
+        const bool unfolds = c->sk_dirty && c->h_sk_counters && c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] != 0;
+        int rc = settle_sk_polled(c);
+        if (rc) return rc;
+        // the unfold just queued changes the table: the launch planner (and the table it saves in front of a risky
+        // launch) must see the table as it will be, not as the poll above found it.  (Without this second poll a
+        // second high-cardinality batch under KMC_ALGO_WALK saved "a small table" that held millions of entries by
+        // the time the snapshot ran: counts of the first batch were lost or KMC_ERR_CAPACITY raised --
+        // tools/stress_sort_lr.py found it, test_walk_two_high_cardinality_batches pins it.)
+        if (unfolds) { rc = poll_and_settle(c); if (rc) return rc; }
+    }
     c->recovered = false;
     c->sorted_valid = false;
     // (for drop_batch_from_table: did this batch start on an empty table?  The counters are as of a poll.)

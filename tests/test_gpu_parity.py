@@ -923,6 +923,27 @@ def test_msd_sort_path_matches_oracle(kmc, oracle, k, pool, n_rec):
         assert kc.export().equals(oracle.count_kmers(hb, ho, k, True, method=1))
 
 
+def test_walk_two_high_cardinality_batches(kmc, oracle):
+    """Two batches of all-distinct reads into one ctx under KMC_ALGO_WALK (no hand-over to the sort path): the first
+    batch leaves most of its counts in the (k+16)-mer table, which is unfolded at the start of the second batch; the
+    launch planner then has to look at the table AFTER that unfold before it saves it in front of a risky launch.
+    (It looked before: the first batch's counts were lost on recovery, or KMC_ERR_CAPACITY was raised.)"""
+    k = 31
+    hb, ho = kmc.synth_reads_host(kmc.Synth(seed=908266423, pool=0), 291, 120859)
+    rng = np.random.default_rng(1)
+    hbn = hb.copy()
+    hbn[rng.integers(0, hb.size, size=hb.size // 5000)] = ord("N")
+    cut = 11624
+    c0 = int(ho[cut])
+    for bases in (hb, hbn):
+        want = oracle.count_kmers(bases, ho, k, True, method=1)
+        for algo in (kmc.ALGO_WALK, kmc.ALGO_AUTO):
+            with kmc.KmerCounter(k=k, algo=algo) as kc:
+                kc.add_batch(bases[:c0], ho[:cut + 1])
+                kc.add_batch(bases[c0:], ho[cut:] - ho[cut])
+                assert kc.export().equals(want), algo
+
+
 @pytest.mark.parametrize("k", [31, 63])
 def test_sort_path_accumulates_batches(kmc, oracle, k, tmp_path):
     """KMC_ALGO_SORT only extracts a batch's keys behind those of the batches before it and sorts when the result is
