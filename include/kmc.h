@@ -110,6 +110,12 @@ typedef struct kmc_stats {
     uint64_t n_slabs_skipped; /* oversize slabs seen by kmc_merge_slabs_device (valid after kmc_finalize) */
     uint64_t n_direct;        /* k-mers the WALK / STREAM kernels counted with one global atomic each because their
                                  LDS memo / partial table was full (valid after kmc_finalize / kmc_poll) */
+    double   kernel_ms_lifetime;  /* like kernel_ms_total, but since kmc_create: kmc_reset does not clear it (a caller that */
+    uint64_t launches_lifetime;   /* resets the ctx per step reads the kernel time of all steps once, after the last) */
+    uint64_t n_async_ok;          /* finalizes of this ctx that produced their view through the small-table kernel, and the oversize */
+    uint64_t n_async_slabs_skipped; /* slabs they saw, both since kmc_create (as of the last call that synchronised): see kmc_finalize_async */
+    uint64_t n_planner_stale;     /* debug invariant of the launch planner: risky launches whose table snapshot was armed on
+                                     counters older than the last queued unfold / merge (must stay 0) */
 } kmc_stats;
 
 const char* kmc_version(void);
@@ -150,12 +156,26 @@ int kmc_merge_pairs_device(kmc_ctx* ctx, const void* d_key_hi, const void* d_key
  * more batches may be added afterwards (the sorted view is then stale until the next finalize). */
 int kmc_finalize(kmc_ctx* ctx, uint64_t* n_distinct, uint64_t* n_total);
 
+/* kmc_finalize for a pipeline that does not want to wait: the device work of a SMALL table's finalize (at most 32768
+ * keys, nothing spilled: every table of generator-style input) is queued on the ctx stream and the call returns.  Behind
+ * it in stream order the sorted view is in place (the pointers kmc_export_device last returned stay valid for small
+ * tables) and the table is empty; kmc_reset after it launches one small kernel and does not wait either.  The next call
+ * that needs the outcome on the host (kmc_finalize, kmc_export*, kmc_add_batch*, ...) synchronises once and takes it from
+ * there -- kmc_finalize then returns the sizes of the view this call produced.  A caller that queues many steps
+ * (count -> kmc_finalize_async -> kmc_reset -> ...) checks afterwards that every step delivered:
+ * kmc_stats.n_async_ok grows by one per finalize that produced its view, n_async_slabs_skipped by the oversize slabs
+ * those finalizes saw (both valid after a synchronising call).  Larger tables are finalized synchronously, as by kmc_finalize. */
+int kmc_finalize_async(kmc_ctx* ctx);
+
 /* Copy the sorted table to caller-allocated host arrays of `cap` entries (cap >= n_distinct).
  * key_hi may be NULL if the caller knows k <= 32. */
 int kmc_export(kmc_ctx* ctx, uint64_t* key_hi, uint64_t* key_lo, uint64_t* count, uint64_t cap);
 
 /* Device pointers to the sorted table of the last kmc_finalize (owned by the ctx, valid until the
- * next finalize/reset/destroy).  d_key_hi is NULL when keys fit one word. */
+ * next finalize/reset/destroy).  d_key_hi is NULL when keys fit one word.
+ * Ordering contract: when kmc_finalize returns, every kernel that writes the view has FINISHED (finalize
+ * synchronises the ctx stream on each of its paths), so the arrays may be read from any stream, by a peer
+ * copy or by a collective without further synchronisation. */
 int kmc_export_device(kmc_ctx* ctx, const void** d_key_hi, const void** d_key_lo,
                       const void** d_count, uint64_t* n_distinct);
 
@@ -270,6 +290,15 @@ int kmc_synth_reads_device(const kmc_synth* s, uint64_t first_record, uint64_t n
                            void* d_bases, void* d_offsets, int device, void* stream);
 /* FASTA text of records [first, first+n) appended to `FILE_ptr` (a FILE*). */
 int kmc_synth_write_fasta(const kmc_synth* s, uint64_t first_record, uint64_t n_records, void* FILE_ptr);
+
+/* ---- measurement aid: the streaming-read rate this GPU actually reaches, so that a kernel's
+ * fraction of the HBM roofline can be quoted against the measured peak beside the nominal 8 TB/s.  A plain
+ * read-only kernel (non-temporal 16-byte loads of [d_buf, d_buf + n_bytes), xor-reduced; no product code) is
+ * launched iters times after one warm-up, bracketed by one hipEvent pair on `stream`; *ms_avg = time per launch.
+ * shape: 0 = the walk kernel's grid (one 1024-thread workgroup per CU), 1 = 8 x 256 threads per CU,
+ * 2 = 2 x 1024 per CU, 3 = 4 x 512 per CU.  *xor_out (may be NULL) receives the checksum that keeps the loads alive. */
+int kmc_read_peak_device(const void* d_buf, uint64_t n_bytes, int device, void* stream, int shape, int iters,
+                         double* ms_avg, uint64_t* xor_out);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,9 @@ class Stats(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("n_bases", C.c_uint64), ("n_kmers", C.c_uint64), ("n_distinct", C.c_uint64),
                 ("table_capacity", C.c_uint64), ("n_spilled", C.c_uint64), ("n_batches", C.c_uint64),
                 ("kernel_ms_last", C.c_double), ("kernel_ms_total", C.c_double), ("algo_last", C.c_int32),
-                ("launches_last", C.c_int32), ("n_slabs_skipped", C.c_uint64), ("n_direct", C.c_uint64)]
+                ("launches_last", C.c_int32), ("n_slabs_skipped", C.c_uint64), ("n_direct", C.c_uint64),
+                ("kernel_ms_lifetime", C.c_double), ("launches_lifetime", C.c_uint64),
+                ("n_async_ok", C.c_uint64), ("n_async_slabs_skipped", C.c_uint64), ("n_planner_stale", C.c_uint64)]
 
 
 class _Reads(C.Structure):
@@ -81,7 +83,7 @@ ABI_SYMBOLS = [
     "kmc_synth_reads_host", "kmc_synth_reads_device", "kmc_synth_write_fasta",
     "kmc_slab_words", "kmc_pack_slab_device", "kmc_merge_slabs_device", "kmc_forget_source",
     "kmc_fasta_stream_open", "kmc_fasta_stream_next", "kmc_fasta_stream_close", "kmc_poll",
-    "kmc_count_file_multi", "kmc_read_pieces", "kmc_sync",
+    "kmc_count_file_multi", "kmc_read_pieces", "kmc_sync", "kmc_read_peak_device", "kmc_finalize_async",
 ]
 
 _lib = None
@@ -143,6 +145,8 @@ def lib() -> C.CDLL:
     L.kmc_forget_source.argtypes = [vp, i32]
     L.kmc_poll.argtypes = [vp]
     L.kmc_sync.argtypes = [vp]
+    L.kmc_finalize_async.argtypes = [vp]
+    L.kmc_read_peak_device.argtypes = [vp, u64, i32, vp, i32, i32, C.POINTER(C.c_double), pu64]
     L.kmc_read_pieces.argtypes = [u64, i32, vp, vp, u64]
     L.kmc_read_pieces.restype = u64
     L.kmc_count_file.argtypes = [vp, C.c_char_p, pu64, pu64]
@@ -360,6 +364,10 @@ class KmerCounter:
         self._chk(self._L.kmc_finalize(self._h, C.byref(nd), C.byref(nt)))
         return nd.value, nt.value
 
+    def finalize_async(self):
+        """Queue the finalize of a small table and return without waiting (kmc_finalize_async)."""
+        self._chk(self._L.kmc_finalize_async(self._h))
+
     def export(self) -> Table:
         nd, _ = self.finalize()
         hi = np.zeros(nd, np.uint64)
@@ -457,3 +465,12 @@ def synth_reads_device(s: Synth, first_record: int, n_records: int, d_bases: int
     rc = lib().kmc_synth_reads_device(C.byref(s), first_record, n_records, d_bases, d_offsets, device, stream or None)
     if rc:
         raise KmcError(rc, lib().kmc_status_string(rc).decode())
+
+
+def read_peak_device(d_buf: int, n_bytes: int, device: int = 0, stream: int = 0, shape: int = 0, iters: int = 5) -> Tuple[float, int]:
+    """Measured streaming-read rate (kmc_read_peak_device): (ms per launch, xor checksum)."""
+    ms, x = C.c_double(), C.c_uint64()
+    rc = lib().kmc_read_peak_device(C.c_void_p(d_buf), int(n_bytes), int(device), C.c_void_p(stream), int(shape), int(iters), C.byref(ms), C.byref(x))
+    if rc:
+        raise KmcError(rc, "kmc_read_peak_device failed")
+    return ms.value, x.value

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <climits>
+#include <deque>
 #include <thread>
 #include <new>
 #include <string>
@@ -29,6 +30,7 @@
 #include "kmc_walk.hip.h"
 #include "kmc_lr.hip.h"
 #include "kmc_msd.hip.h"
+#include "kmc_peak.hip.h"
 #include "kmc_ingest.h"
 
 namespace {
@@ -59,7 +61,17 @@ struct kmc_ctx {
     u64* d_counters = nullptr;      // KMC_CTR_N u64
     u64* h_counters = nullptr;      // pinned mirror
     u64* occ_list = nullptr;        // first KMC_OCC_LIST_CAP claimed slots (fast finalize of small tables)
-    u32* fin_rank = nullptr;        // rank[KMC_OCC_LIST_CAP] + ticket counter of kmc_small_finalize_kernel (zero between launches)
+    u32* fin_rank = nullptr;        // ticket counter of kmc_small_finalize_kernel (zero between launches)
+    u64* d_mirror = nullptr;        // h_counters as the device sees it (the finalize kernel publishes the counters there)
+    u64* h_restore = nullptr;       // pinned: the counters to put back when a drained table is filled again (undrain)
+    // planner invariant (kmc_stats.n_planner_stale): every kernel queued OUTSIDE the count launches' own accounting that
+    // changes the table -- the (k+16)-mer unfold, merges -- bumps table_epoch; a poll records the epoch it has seen; a
+    // risky launch must save a table whose counters were polled at the current epoch
+    u64 table_epoch = 0, polled_epoch = 0;
+    u64 fin_seq = 0;                // number of the last kmc_small_finalize_kernel launch (the kernel publishes it with its result)
+    bool async_fin = false;         // kmc_finalize_async: a finalize is queued whose outcome the host has not looked at yet
+    bool drained = false;           // the last kmc_finalize emptied the table into the sorted view (kmc_small_finalize_kernel):
+                                    // table and device counters are as after kmc_reset, h_counters hold the true totals
     u64 *spill_hi = nullptr, *spill_lo = nullptr, *spill_cnt = nullptr;
     u64 spill_cap = 0;
 
@@ -95,13 +107,14 @@ struct kmc_ctx {
     bool msd_dup_heavy = false;  // the last large unweighted sort collapsed its keys more than fourfold (leaf size of two-word sorts)
     bool prefer_sort = false;  // AUTO: the data source proved high-cardinality  // per-workgroup memo slots, kept across launches (kmc_walk.hip.h)
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;  // bracket the whole batch
-    std::vector<hipEvent_t> lev;              // pairs bracketing every count-kernel launch of the batch
-    size_t lev_used = 0;
+    // hipEvent pairs bracketing every count-kernel launch, batch by batch: a batch's events are read once they have
+    // completed (harvest_timing), possibly several batches later -- a caller that never synchronises this ctx (the
+    // multi-GPU step: count, pack, reset) still gets every batch's kernel time into kernel_ms_lifetime
+    std::deque<std::vector<hipEvent_t>> tb;   // batches whose events have not been read yet (front = oldest)
+    std::vector<hipEvent_t> ev_free;          // events to reuse
     kmc_stats st{};
     int fin_parity = 0;    // which OUT/SUM counter pair the next kmc_finalize uses
     u64 fin_hint = 0;      // table entries at the last kmc_finalize (sizes the next speculative small-table finalize)
-    bool timed = false;    // ev0/ev1 bracket a finished batch
     bool batch_pending = false;  // a COUNT kernel (unknown number of new keys) is queued since the last poll
     u64 unpolled_adds = 0;       // upper bound of keys added by merge kernels since the last poll
     bool walk_overflowed = false;  // the last WALK/STREAM launches counted >5% of their k-mers with global atomics
@@ -321,7 +334,7 @@ void sk_free(kmc_ctx* c) {
     u64** p[] = {&c->sk_spill_hi, &c->sk_spill_lo, &c->sk_spill_cnt, &c->sk_spill_mid, &c->sk_occ};
     for (u64** q : p) { if (*q) (void)hipFree(*q); *q = nullptr; }
 }
-int sk_alloc(kmc_ctx* c, u64 cap) {
+int sk_alloc_parts(kmc_ctx* c, u64 cap) {
     const bool three = c->cfg.k > KMC_SK_MAX_K;  // a (k+16)-mer of more than 63 bases: three key words
     c->sk.cap = cap;
     HIPCHK(c, hipMalloc((void**)&c->sk.hi, cap * sizeof(u64)));
@@ -337,6 +350,14 @@ int sk_alloc(kmc_ctx* c, u64 cap) {
     if (three) HIPCHK(c, hipMalloc((void**)&c->sk_spill_mid, c->sk_spill_cap * sizeof(u64)));
     HIPCHK(c, hipMalloc((void**)&c->sk_occ, cap * sizeof(u64)));
     return sk_clear(c);
+}
+// all or nothing: a table whose spill area or slot list is missing must never reach a kernel (kmc_spill writes
+// spill_lo[idx] unconditionally), so a failed allocation leaves NO second-level memo -- the walk then runs
+// without it, or the next batch repeats the error cleanly
+int sk_alloc(kmc_ctx* c, u64 cap) {
+    const int rc = sk_alloc_parts(c, cap);
+    if (rc) { sk_free(c); c->sk_spill_cap = 0; }
+    return rc;
 }
 int sk_ensure(kmc_ctx* c) {
     if (c->sk.lo || c->cfg.mode != KMC_MODE_CONTIG) return KMC_OK;
@@ -372,10 +393,32 @@ int grid_for(const kmc_ctx* c, u64 n, int threads) {
 template <typename F1, typename F2>
 auto kw_dispatch(int KW, F1 f1, F2 f2) { return KW == 1 ? f1() : f2(); }
 
+// what a poll learns from fresh h_counters
+int poll_book(kmc_ctx* c);
 // read the device counters (synchronises the stream)
 int poll(kmc_ctx* c) {
     HIPCHK(c, hipMemcpyAsync(c->h_counters, c->d_counters, (c->sk.lo ? 2 : 1) * KMC_CTR_N * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    return poll_book(c);
+}
+// The poll right behind a speculative kmc_small_finalize_kernel: when the kernel succeeded it has PUBLISHED the
+// counters to h_counters itself (and emptied the table): no read-back copy, one synchronisation.
+int poll_fin(kmc_ctx* c) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->st.n_async_ok = c->h_counters[KMC_CTR_FINOK];
+    c->st.n_async_slabs_skipped = c->h_counters[KMC_CTR_FINSKIP];
+    if (c->h_counters[KMC_CTR_FASTFIN] != 1 || c->h_counters[KMC_CTR_FINSEQ] != c->fin_seq) {   // it gave up: read the counters the usual way
+        c->h_counters[KMC_CTR_FASTFIN] = 0;
+        int rc = poll(c);
+        c->h_counters[KMC_CTR_FASTFIN] = 0;   // (the device word is never written; whatever the copy brought is not a verdict)
+        return rc;
+    }
+    c->drained = true;
+    c->fin_parity = 0;
+    return poll_book(c);
+}
+int poll_book(kmc_ctx* c) {
+    c->polled_epoch = c->table_epoch;
     c->pending = false;
     c->batch_pending = false;
     c->unpolled_adds = 0;
@@ -478,6 +521,67 @@ int poll_and_settle(kmc_ctx* c) {
     if (rc) return rc;
     return settle(c);
 }
+int poll_fin_and_settle(kmc_ctx* c) {
+    int rc = poll_fin(c);
+    if (rc) return rc;
+    return settle(c);
+}
+
+// The speculative small-table finalize (kmc_table.hip.h): queued behind whatever is still running.
+int launch_small_finalize(kmc_ctx* c, int grid) {
+    GTable g = gtable_of(c, c->tab);
+    // the kernel publishes {FASTFIN, FINSEQ = seq, the counters} through d_mirror; the host trusts a verdict only
+    // when it carries this launch's number (earlier launches may still be in flight: kmc_finalize_async)
+    const u64 seq = ++c->fin_seq;
+    const u64* skc = c->d_counters + KMC_CTR_N;
+    if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(grid), dim3(1024), 0, c->stream, g, skc, c->fin_rank, c->d_mirror, seq, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+    else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(grid), dim3(1024), 0, c->stream, g, skc, c->fin_rank, c->d_mirror, seq, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
+    HIPCHK(c, hipGetLastError());
+    return KMC_OK;
+}
+
+// A finalize that drained the table (c->drained) left the counts in the sorted view only.  Before anything adds
+// to the table again -- a further batch, a merge -- the view's pairs go back in and the counters are restored.
+// Nothing is synchronised: h_counters already hold what the device counters will read once the merge has run.
+int undrain(kmc_ctx* c) {
+    if (!c->drained) return KMC_OK;
+    c->drained = false;
+    memcpy(c->h_restore, c->h_counters, KMC_CTR_N * sizeof(u64));
+    const int zero[] = {KMC_CTR_OCCUPIED, KMC_CTR_OUT, KMC_CTR_SUM, KMC_CTR_OUT1, KMC_CTR_SUM1, KMC_CTR_SUM2, KMC_CTR_FASTFIN};
+    for (int i : zero) c->h_restore[i] = 0;   // (the merge claims the slots again and counts them)
+    HIPCHK(c, hipMemcpyAsync(c->d_counters, c->h_restore, KMC_CTR_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
+    c->fin_parity = 0;
+    const u64 n = c->n_sorted;
+    if (n) {
+        GTable g = gtable_of(c, c->tab);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_merge_pairs_kernel<1>, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, g, (const u64*)nullptr, (const u64*)c->o_lo.p, (const u64*)c->o_cnt.p, n);
+        else hipLaunchKernelGGL(kmc_merge_pairs_kernel<2>, dim3(grid_for(c, n, 256)), dim3(256), 0, c->stream, g, (const u64*)c->o_hi.p, (const u64*)c->o_lo.p, (const u64*)c->o_cnt.p, n);
+        HIPCHK(c, hipGetLastError());
+    }
+    return KMC_OK;
+}
+
+// kmc_finalize_async queued a finalize and returned; before the host does anything else with the ctx it has to learn
+// how that went (one synchronisation): a view + a drained table, or "gave up" and a table that is as it was.
+int resolve_async(kmc_ctx* c) {
+    if (!c->async_fin) return KMC_OK;
+    c->async_fin = false;
+    int rc = poll_fin(c);
+    if (rc) return rc;
+    if (c->drained) {
+        const u64 n = c->h_counters[KMC_CTR_OCCUPIED];
+        c->v_hi = c->KW == 2 ? (const u64*)c->o_hi.p : nullptr;
+        c->v_lo = (const u64*)c->o_lo.p;
+        c->v_cnt = (const u64*)c->o_cnt.p;
+        c->n_sorted = n;
+        c->sorted_valid = true;
+        c->fin_hint = n;
+        c->st.n_distinct = n;
+        c->st.n_kmers = n ? c->h_counters[KMC_CTR_SUM2] : 0;
+        return KMC_OK;
+    }
+    return settle(c);
+}
 
 // Give the counts of the (k+16)-mer table to their k-mers (kmc_sk_unfold_kernel).  What the last poll
 // saw of that table is certain to come (16 k-mers per entry): room is made for it first.  Entries
@@ -499,6 +603,7 @@ int flush_sk(kmc_ctx* c) {
     if (r) return fail(c, r, "(k+16)-mer unfold launch failed");
     c->sk_dirty = false;
     c->pending = true;
+    c->table_epoch++;
     return sk_regrow(c);
 }
 
@@ -512,20 +617,25 @@ int settle_sk_polled(kmc_ctx* c) {
 // ---- launching the counting kernels ---------------------------------------------------------
 
 // hipEvent pair around one count-kernel launch; the sum over a batch is kmc_stats.kernel_ms_last
+int take_event(kmc_ctx* c, hipEvent_t* e) {
+    if (!c->ev_free.empty()) { *e = c->ev_free.back(); c->ev_free.pop_back(); return KMC_OK; }
+    HIPCHK(c, hipEventCreate(e));
+    return KMC_OK;
+}
 int launch_begin(kmc_ctx* c) {
-    if (c->lev_used + 2 > c->lev.size()) {
-        for (int i = 0; i < 2; ++i) {
-            hipEvent_t e;
-            HIPCHK(c, hipEventCreate(&e));
-            c->lev.push_back(e);
-        }
-    }
-    HIPCHK(c, hipEventRecord(c->lev[c->lev_used], c->stream));
+    if (c->tb.empty()) c->tb.emplace_back();
+    if (c->tb.back().size() & 1) { c->ev_free.push_back(c->tb.back().back()); c->tb.back().pop_back(); }   // (a bracket left open by a failed launch)
+    hipEvent_t e;
+    { int rc = take_event(c, &e); if (rc) return rc; }
+    c->tb.back().push_back(e);
+    HIPCHK(c, hipEventRecord(e, c->stream));
     return KMC_OK;
 }
 int launch_end(kmc_ctx* c) {
-    HIPCHK(c, hipEventRecord(c->lev[c->lev_used + 1], c->stream));
-    c->lev_used += 2;
+    hipEvent_t e;
+    { int rc = take_event(c, &e); if (rc) return rc; }
+    c->tb.back().push_back(e);
+    HIPCHK(c, hipEventRecord(e, c->stream));
     c->batch_pending = true;
     return KMC_OK;
 }
@@ -777,6 +887,7 @@ int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
 // large to be saved cheaply: the caller then keeps the launch within what is certain to fit.
 bool arm_risky(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 base_from, const u64* d_from) {
     const u64 occ = c->h_counters[KMC_CTR_OCCUPIED];
+    if (c->polled_epoch != c->table_epoch) c->st.n_planner_stale++;   // (the counters this decision rests on are older than a queued unfold / merge)
     kmc_ctx::Risky& r = c->risky;
     GTable g = gtable_of(c, c->tab);
     r.empty = false;
@@ -830,8 +941,8 @@ int recover_overflow(kmc_ctx* c) {
         }
         if (n_snap == ~0ull) return fail(c, KMC_ERR_CAPACITY, "count table and spill area exhausted and the table could not be restored; raise capacity_hint");
         const int grid = grid_for(c, c->tab.cap, 256);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g);
-        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
+        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
         ctr[KMC_CTR_OCCUPIED] = 0;  // (the merge below claims the slots again and counts them)
         HIPCHK(c, hipMemcpyAsync(c->d_counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, c->stream));
         if (n_snap) {
@@ -874,8 +985,8 @@ int recover_overflow(kmc_ctx* c) {
 int drop_batch_from_table(kmc_ctx* c, const u64* ctr0) {
     GTable g = gtable_of(c, c->tab);
     const int grid = grid_for(c, c->tab.cap, 256);
-    if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g);
-    else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g);
+    if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
+    else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->d_counters, ctr0, KMC_CTR_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     { int rs = sk_clear(c); if (rs) return rs; }
@@ -922,7 +1033,10 @@ int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
     return KMC_OK;
 }
 
+void harvest_timing(kmc_ctx* c);
 int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len) {
+    { int rc = resolve_async(c); if (rc) return rc; }
+    { int rc = undrain(c); if (rc) return rc; }
     if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
     // the previous batch's (k+16)-mer counts, if it left any: the counters are as of a poll that came after
     // its last launch (every launch sets `pending`), so an empty table is known to be empty
@@ -968,8 +1082,8 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     }
     c->st.algo_last = algo;
 
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    c->lev_used = 0;
+    harvest_timing(c);       // (batches that have finished since; never waits)
+    c->tb.emplace_back();    // this batch's launch events
     int rc = KMC_OK;
     {
         // Sub-batches.  A launch over n k-mers can add at most n new keys, so without history the
@@ -1242,25 +1356,36 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
         c->b_rho_max = batch_rho_max;  // the last launch's share is folded in by the next poll()
         c->b_open = true;
     }
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    c->timed = true;
     return KMC_OK;
 }
 
 // kernel time of the last batch = sum over its count-kernel launches (host polls between sub-batches
 // are not kernel time).  Only once the batch has finished on the GPU.
 void harvest_timing(kmc_ctx* c) {
-    if (!c->timed || c->lev_used < 2) return;
-    if (hipEventQuery(c->lev[c->lev_used - 1]) != hipSuccess) { (void)hipGetLastError(); return; }
-    float ms = 0.f;
-    double sum = 0.0;
-    for (size_t i = 0; i + 1 < c->lev_used; i += 2) {
-        if (hipEventElapsedTime(&ms, c->lev[i], c->lev[i + 1]) == hipSuccess) sum += ms; else (void)hipGetLastError();
+    while (!c->tb.empty()) {
+        std::vector<hipEvent_t>& b = c->tb.front();
+        const bool current = c->tb.size() == 1;   // (the newest batch may still be queueing launches: leave it until it is complete AND idle)
+        if (b.size() >= 2 && (b.size() & 1) == 0) {
+            hipError_t q = hipEventQuery(b.back());
+            if (q != hipSuccess && c->tb.size() > 64) q = hipEventSynchronize(b.back());   // (bounded backlog)
+            if (q != hipSuccess) { (void)hipGetLastError(); return; }
+            float ms = 0.f;
+            double sum = 0.0;
+            for (size_t i = 0; i + 1 < b.size(); i += 2) {
+                if (hipEventElapsedTime(&ms, b[i], b[i + 1]) == hipSuccess) sum += ms; else (void)hipGetLastError();
+            }
+            c->st.kernel_ms_last = sum;
+            c->st.kernel_ms_total += sum;
+            c->st.kernel_ms_lifetime += sum;
+            c->st.launches_last = (int32_t)(b.size() / 2);  // launches in that batch
+            c->st.launches_lifetime += b.size() / 2;
+        } else if (!b.empty() && current) {
+            return;   // (an odd number: a launch is being bracketed right now)
+        }
+        for (hipEvent_t e : b) c->ev_free.push_back(e);
+        c->tb.pop_front();
+        (void)current;
     }
-    c->st.kernel_ms_last = sum;
-    c->st.kernel_ms_total += sum;
-    c->st.launches_last = (int32_t)(c->lev_used / 2);  // launches in the last batch
-    c->timed = false;
 }
 
 }  // namespace
@@ -1294,6 +1419,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     free_table(c->tab);
     if (c->d_counters) (void)hipFree(c->d_counters);
     if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->h_restore) (void)hipHostFree(c->h_restore);
     if (c->occ_list) (void)hipFree(c->occ_list);
     if (c->fin_rank) (void)hipFree(c->fin_rank);
     if (c->spill_hi) (void)hipFree(c->spill_hi);
@@ -1309,9 +1435,8 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     sk_free(c);
     try { free_runs(c, true); } catch (...) { /* (only the pool bookkeeping can throw; the buffers it could not list leak with the process) */ }
     for (DevBuf* b : bufs) free_buf(*b);
-    for (hipEvent_t e : c->lev) (void)hipEventDestroy(e);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    for (auto& b : c->tb) for (hipEvent_t e : b) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1340,17 +1465,17 @@ static int kmc_create_impl(kmc_ctx** out, const kmc_config* cfg) {
         c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (cfg->stream) c->stream = (hipStream_t)cfg->stream;
         else { HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)); c->own_stream = true; }
-        HIPCHK(c, hipEventCreate(&c->ev0));
-        HIPCHK(c, hipEventCreate(&c->ev1));
         HIPCHK(c, hipMalloc((void**)&c->d_counters, 2 * KMC_CTR_N * sizeof(u64)));  // [count table | (k+16)-mer table]: one read-back
         HIPCHK(c, hipMemsetAsync(c->d_counters, 0, 2 * KMC_CTR_N * sizeof(u64), c->stream));
         HIPCHK(c, hipHostMalloc((void**)&c->h_counters, 2 * KMC_CTR_N * sizeof(u64)));
         memset(c->h_counters, 0, 2 * KMC_CTR_N * sizeof(u64));
+        HIPCHK(c, hipHostGetDevicePointer((void**)&c->d_mirror, c->h_counters, 0));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_restore, KMC_CTR_N * sizeof(u64)));
         u64 cap = next_pow2(std::max<u64>(cfg->capacity_hint * 2, 1ull << 20));
         c->spill_cap = std::max<u64>(cap / 4, 1ull << 18);
         HIPCHK(c, hipMalloc((void**)&c->occ_list, KMC_OCC_LIST_CAP * sizeof(u64)));
-        HIPCHK(c, hipMalloc((void**)&c->fin_rank, (KMC_OCC_LIST_CAP + 16) * sizeof(u32)));
-        HIPCHK(c, hipMemsetAsync(c->fin_rank, 0, (KMC_OCC_LIST_CAP + 16) * sizeof(u32), c->stream));
+        HIPCHK(c, hipMalloc((void**)&c->fin_rank, 16 * sizeof(u32)));
+        HIPCHK(c, hipMemsetAsync(c->fin_rank, 0, 16 * sizeof(u32), c->stream));
         HIPCHK(c, hipMalloc((void**)&c->spill_lo, c->spill_cap * sizeof(u64)));
         HIPCHK(c, hipMalloc((void**)&c->spill_cnt, c->spill_cap * sizeof(u64)));
         if (c->KW == 2) HIPCHK(c, hipMalloc((void**)&c->spill_hi, c->spill_cap * sizeof(u64)));
@@ -1373,12 +1498,29 @@ static int kmc_create_impl(kmc_ctx** out, const kmc_config* cfg) {
 static int kmc_reset_impl(kmc_ctx* c) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
-    if (c->sk_dirty) { int r = flush_sk(c); if (r) return r; }  // (empties the (k+16)-mer table; its counts go with the table)
-    {
+    if (c->async_fin) {
+        // a finalize is queued whose outcome nobody has looked at (kmc_finalize_async): it has drained the table or left it
+        // as it was -- the reset kernel decides on the device, nothing waits
+        c->async_fin = false;
+        c->drained = false;
+        c->sk_dirty = false;   // (kmc_finalize_async queued the unfold in front of its kernel)
         GTable g = gtable_of(c, c->tab);
         int grid = grid_for(c, c->tab.cap, 256);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g);
-        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
+        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
+        HIPCHK(c, hipGetLastError());
+        c->fin_parity = 0;
+    } else if (c->drained) {
+        // the last kmc_finalize emptied the table into its sorted view (kmc_small_finalize_kernel): table and device
+        // counters are already what the reset kernel would leave -- nothing to launch
+        c->drained = false;
+        c->fin_parity = 0;
+    } else {
+        if (c->sk_dirty) { int r = flush_sk(c); if (r) return r; }  // (empties the (k+16)-mer table; its counts go with the table)
+        GTable g = gtable_of(c, c->tab);
+        int grid = grid_for(c, c->tab.cap, 256);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
+        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
         HIPCHK(c, hipGetLastError());
         c->fin_parity = 0;
     }
@@ -1393,9 +1535,14 @@ static int kmc_reset_impl(kmc_ctx* c) {
     c->b_open = false;  // (rho_hist itself is kept: it describes the data source)
     c->risky.armed = false;
     c->recovered = false;
-    u64 cap = c->st.table_capacity;
+    const kmc_stats keep = c->st;
     c->st = kmc_stats{};
-    c->st.table_capacity = cap;
+    c->st.table_capacity = keep.table_capacity;
+    c->st.kernel_ms_lifetime = keep.kernel_ms_lifetime;
+    c->st.launches_lifetime = keep.launches_lifetime;
+    c->st.n_planner_stale = keep.n_planner_stale;
+    c->st.n_async_ok = keep.n_async_ok;
+    c->st.n_async_slabs_skipped = keep.n_async_slabs_skipped;
     return KMC_OK;
 }
 
@@ -1437,6 +1584,8 @@ static int kmc_merge_pairs_device_impl(kmc_ctx* c, const void* d_key_hi, const v
     if (!n) return KMC_OK;
     if (!d_key_lo || !d_count) return fail(c, KMC_ERR_ARG, "null device pointer");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rc = resolve_async(c); if (rc) return rc; }
+    { int rc = undrain(c); if (rc) return rc; }
     // make room for the worst case (every pair new).  Merges queued since the last poll are
     // accounted with their upper bound, so a series of merges (one per peer in the multi-GPU reduce)
     // needs no host synchronisation in between.
@@ -1456,6 +1605,7 @@ static int kmc_merge_pairs_device_impl(kmc_ctx* c, const void* d_key_hi, const v
     else hipLaunchKernelGGL(kmc_merge_pairs_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (const u64*)d_key_hi, (const u64*)d_key_lo, (const u64*)d_count, n);
     HIPCHK(c, hipGetLastError());
     c->pending = true;
+    c->table_epoch++;
     return KMC_OK;
 }
 
@@ -1465,6 +1615,14 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     int rc;
     bool tried_fast = false;
     int fgrid_used = 0;
+    rc = resolve_async(c);   // (a finalize queued by kmc_finalize_async: its view, when it produced one, is the result)
+    if (rc) return rc;
+    if (c->drained && c->sorted_valid) {  // nothing was added since the last finalize (which emptied the table into the view)
+        harvest_timing(c);
+        if (n_distinct) *n_distinct = c->n_sorted;
+        if (n_total) *n_total = c->st.n_kmers;
+        return KMC_OK;
+    }
     rc = flush_acc(c);  // keys the sort path has extracted since the last flush: one run
     if (rc) return rc;
     if (c->runs.empty()) {
@@ -1473,17 +1631,15 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         rc = ensure(c, c->o_lo, fb); if (rc) return rc;
         rc = ensure(c, c->o_cnt, fb); if (rc) return rc;
         if (c->KW == 2) { rc = ensure(c, c->o_hi, fb); if (rc) return rc; }
-        GTable g = gtable_of(c, c->tab);
         // one workgroup per 64 keys; the grid follows the size of the last table seen (x2), at least 128
         // workgroups: 512 workgroups of which 460 leave at once cost 3 us more than 128 on the benchmark's
         // 3,350 keys.  A table that outgrew the grid is noticed below and finalized again with the full grid.
         fgrid_used = (int)std::min<u64>(KMC_OCC_LIST_CAP / KMC_FIN_CHUNK, std::max<u64>(128, next_pow2(2 * c->fin_hint / KMC_FIN_CHUNK + 1)));
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
-        else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
-        HIPCHK(c, hipGetLastError());
+        rc = launch_small_finalize(c, fgrid_used);
+        if (rc) return rc;
         tried_fast = true;
     }
-    rc = poll_and_settle(c);
+    rc = tried_fast ? poll_fin_and_settle(c) : poll_and_settle(c);
     if (!rc && c->acc_n) rc = flush_acc(c);  // (the poll may have recovered an overflow by extracting the rest of a batch)
     if (rc) return rc;
     if (c->sk_dirty) {
@@ -1492,14 +1648,16 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         rc = settle_sk_polled(c);
         if (rc) return rc;
         if (had) {  // the table changed under the speculative finalize: once more
+            // (the unfold just queued fills the table: the poll behind it may find it grown or spilled -- settled there;
+            // the second finalize kernel sees the (k+16)-mer table empty again and may drain)
+            bool again = false;
             if (tried_fast && c->runs.empty()) {
-                GTable g = gtable_of(c, c->tab);
                 fgrid_used = KMC_OCC_LIST_CAP / KMC_FIN_CHUNK;
-                if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
-                else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
-                HIPCHK(c, hipGetLastError());
+                rc = launch_small_finalize(c, fgrid_used);
+                if (rc) return rc;
+                again = true;
             }
-            rc = poll_and_settle(c);
+            rc = again ? poll_fin_and_settle(c) : poll_and_settle(c);
     if (!rc && c->acc_n) rc = flush_acc(c);  // (the poll may have recovered an overflow by extracting the rest of a batch)
             if (rc) return rc;
         }
@@ -1508,12 +1666,10 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     if (tried_fast && c->runs.empty() && c->h_counters[KMC_CTR_FASTFIN] != 1 && c->h_counters[KMC_CTR_SPILL] == 0 &&
         c->h_counters[KMC_CTR_OCCUPIED] > (u64)fgrid_used * KMC_FIN_CHUNK && c->h_counters[KMC_CTR_OCCUPIED] <= KMC_OCC_LIST_CAP) {
         // the table outgrew the speculative grid (first finalize of a larger source): once more, full grid
-        GTable g = gtable_of(c, c->tab);
         fgrid_used = KMC_OCC_LIST_CAP / KMC_FIN_CHUNK;
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_small_finalize_kernel<1>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)nullptr, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
-        else hipLaunchKernelGGL(kmc_small_finalize_kernel<2>, dim3(fgrid_used), dim3(1024), 0, c->stream, g, c->fin_rank, (u64*)c->o_hi.p, (u64*)c->o_lo.p, (u64*)c->o_cnt.p);
-        HIPCHK(c, hipGetLastError());
-        rc = poll_and_settle(c);
+        rc = launch_small_finalize(c, fgrid_used);
+        if (rc) return rc;
+        rc = poll_fin_and_settle(c);
     if (!rc && c->acc_n) rc = flush_acc(c);  // (the poll may have recovered an overflow by extracting the rest of a batch)
         if (rc) return rc;
     }
@@ -1572,6 +1728,11 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         const size_t before = c->runs.size();
         rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen, c->KW);
         if (rc) return rc;
+        // The merged view is read by other streams right after this call (kmc_export_device consumers, the
+        // peer copies of kmc_count_file_multi on the destination ctx's stream): unlike the fast and single-run
+        // branches, whose view was complete before the poll above synchronised, this one's last kernels are
+        // still queued -- wait for them (it is already a multi-synchronisation path).
+        HIPCHK(c, hipStreamSynchronize(c->stream));
         if (c->runs.size() > before) {
             c->view_run = c->runs.back();   // the merged view is not one of the ctx's runs (they stay as they are)
             c->runs.pop_back();
@@ -1592,8 +1753,30 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     return KMC_OK;
 }
 
+// kmc_finalize without the wait, for small tables: the unfold of pending (k+16)-mer counts and the small-table finalize
+// are queued behind the work in flight and the call returns.  Anything but a small table (sorted runs, extracted keys)
+// is finalized the ordinary, synchronous way.
+static int kmc_finalize_async_impl(kmc_ctx* c) {
+    if (!c) return KMC_ERR_ARG;
+    HIPCHK(c, hipSetDevice(c->cfg.device));
+    if (c->async_fin || (c->drained && c->sorted_valid)) return KMC_OK;   // (queued already / final already)
+    if (!c->runs.empty() || c->acc_n) return kmc_finalize(c, nullptr, nullptr);
+    const size_t fb = (size_t)KMC_OCC_LIST_CAP * sizeof(u64);
+    int rc = ensure(c, c->o_lo, fb); if (rc) return rc;
+    rc = ensure(c, c->o_cnt, fb); if (rc) return rc;
+    if (c->KW == 2) { rc = ensure(c, c->o_hi, fb); if (rc) return rc; }
+    if (c->sk_dirty) { rc = flush_sk(c); if (rc) return rc; }
+    const int grid = (int)std::min<u64>(KMC_OCC_LIST_CAP / KMC_FIN_CHUNK, std::max<u64>(128, next_pow2(2 * c->fin_hint / KMC_FIN_CHUNK + 1)));
+    rc = launch_small_finalize(c, grid);
+    if (rc) return rc;
+    c->async_fin = true;
+    c->sorted_valid = false;   // (until somebody has looked)
+    return KMC_OK;
+}
+
 static int kmc_export_impl(kmc_ctx* c, uint64_t* key_hi, uint64_t* key_lo, uint64_t* count, uint64_t cap) {
     if (!c) return KMC_ERR_ARG;
+    { int rc = resolve_async(c); if (rc) return rc; }
     if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_export before kmc_finalize");
     const u64 n = c->n_sorted;
     if (cap < n) return fail(c, KMC_ERR_ARG, "export capacity %llu < %llu distinct keys", (unsigned long long)cap, (unsigned long long)n);
@@ -1612,6 +1795,7 @@ static int kmc_export_impl(kmc_ctx* c, uint64_t* key_hi, uint64_t* key_lo, uint6
 
 static int kmc_export_device_impl(kmc_ctx* c, const void** d_key_hi, const void** d_key_lo, const void** d_count, uint64_t* n_distinct) {
     if (!c) return KMC_ERR_ARG;
+    { int rc = resolve_async(c); if (rc) return rc; }
     if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_export_device before kmc_finalize");
     if (d_key_hi) *d_key_hi = c->KW == 2 ? c->v_hi : nullptr;
     if (d_key_lo) *d_key_lo = c->v_lo;
@@ -1625,6 +1809,7 @@ extern "C" uint32_t kmc_owner_of(uint64_t key_hi, uint64_t key_lo, uint32_t n_pa
 static int kmc_partition_device_impl(kmc_ctx* c, uint32_t n_parts, uint64_t* part_begin, const void** d_key_hi,
                                     const void** d_key_lo, const void** d_count) {
     if (!c || !n_parts || !part_begin) return KMC_ERR_ARG;
+    { int rc = resolve_async(c); if (rc) return rc; }
     if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_partition_device before kmc_finalize");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     const u64 n = c->n_sorted;
@@ -1672,6 +1857,7 @@ static int kmc_pack_slab_device_impl(kmc_ctx* c, void* d_slab, uint64_t slab_ent
     if (!c || !d_slab || !slab_entries) return c ? fail(c, KMC_ERR_ARG, "kmc_pack_slab_device: null slab or zero capacity") : KMC_ERR_ARG;
     if (((uintptr_t)d_slab & 7) != 0) return fail(c, KMC_ERR_ARG, "d_slab must be 8-byte aligned");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rc = resolve_async(c); if (rc) return rc; }
     if (c->sk_dirty) { int r = flush_sk(c); if (r) return r; }
     if (!c->sorted_valid) {
         // not finalized: pack the live table (unsorted) -- the device decides whether it fits
@@ -1697,6 +1883,8 @@ static int kmc_merge_slabs_device_impl(kmc_ctx* c, const void* d_slabs, uint32_t
     if (!d_slabs || !n_slabs || !slab_entries || !n_parts || my_part >= n_parts) return fail(c, KMC_ERR_ARG, "kmc_merge_slabs_device: bad argument");
     if (((uintptr_t)d_slabs & 7) != 0) return fail(c, KMC_ERR_ARG, "d_slabs must be 8-byte aligned");
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rc = resolve_async(c); if (rc) return rc; }
+    { int rc = undrain(c); if (rc) return rc; }
     // room for the worst case (every pair of every slab new and owned here), accounted like
     // kmc_merge_pairs_device so that a reset table needs no host synchronisation
     const u64 n = (u64)n_slabs * slab_entries;
@@ -1717,6 +1905,7 @@ static int kmc_merge_slabs_device_impl(kmc_ctx* c, const void* d_slabs, uint32_t
     else hipLaunchKernelGGL(kmc_merge_slabs_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (const u64*)d_slabs, n_slabs, words, slab_entries, my_part, n_parts);
     HIPCHK(c, hipGetLastError());
     c->pending = true;
+    c->table_epoch++;
     return KMC_OK;
 }
 
@@ -1732,6 +1921,12 @@ extern "C" uint64_t kmc_read_pieces(uint64_t read_len, int k, uint64_t* starts, 
 static int kmc_poll_impl(kmc_ctx* c) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rc = resolve_async(c); if (rc) return rc; }
+    if (c->drained) {  // (nothing can be pending behind a finalize; the device counters are zero, h_counters hold the totals)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        harvest_timing(c);
+        return KMC_OK;
+    }
     int rc = poll_and_settle(c);
     if (rc) return rc;
     if (c->runs.empty() && !c->acc_n) c->st.n_kmers = c->h_counters[KMC_CTR_KMERS];  // (the sort path counts at finalize)
@@ -1742,11 +1937,23 @@ static int kmc_poll_impl(kmc_ctx* c) {
 static int kmc_forget_source_impl(kmc_ctx* c, int what) {
     if (!c) return KMC_ERR_ARG;
     HIPCHK(c, hipSetDevice(c->cfg.device));
+    { int rc = resolve_async(c); if (rc) return rc; }
     if ((what & KMC_FORGET_MEMO) && c->walk_memo.p) {
         HIPCHK(c, hipMemsetAsync(c->walk_memo.p, 0, kmc_walk_memo_bytes(c->n_cu, c->KW), c->stream));  // tag 0 = no snapshot
         c->memo_parity = 0;
     }
-    if (what & KMC_FORGET_MEMO) { int rs = sk_clear(c); if (rs) return rs; }
+    if (what & KMC_FORGET_MEMO) {
+        // the (k+16)-mer table holds COUNTS as well as structure (walk launches add to it, the unfold into the
+        // count table is deferred): give them to their k-mers first -- stream order puts the unfold ahead of
+        // the memsets -- so that forgetting the source never touches counts
+        if (c->sk_dirty) {
+            if (c->pending) { int rp = poll_and_settle(c); if (rp) return rp; }   // (sizes the unfold exactly; recovers a wrong prediction first)
+            int rf = settle_sk_polled(c);
+            if (rf) return rf;
+        }
+        int rs = sk_clear(c);
+        if (rs) return rs;
+    }
     if (what & KMC_FORGET_HISTORY) {
         c->rho_hist = -1.0;
         c->rho_last = c->rho_max = 0.0;
@@ -2047,6 +2254,49 @@ static int kmc_synth_reads_device_impl(const kmc_synth* s, uint64_t first_record
     return e == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
 
+// Measured streaming-read peak (kmc_peak.hip.h): `iters` launches of the plain read kernel over
+// [d_buf, d_buf + n_bytes) after one warm-up launch, bracketed by one hipEvent pair on `stream`.
+static int kmc_read_peak_device_impl(const void* d_buf, uint64_t n_bytes, int device, void* stream, int shape, int iters,
+                                     double* ms_avg, uint64_t* xor_out) {
+    if (!d_buf || n_bytes < 16 || iters < 1 || !ms_avg || ((uintptr_t)d_buf & 15) != 0) return KMC_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return KMC_ERR_NO_DEVICE;
+    hipStream_t st = (hipStream_t)stream;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return KMC_ERR_HIP;
+    const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    unsigned long long* d_out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    int rc = KMC_OK;
+    float ms = 0.f;
+    unsigned long long h = 0;
+    const u64 n16 = n_bytes / 16;
+    auto launch = [&]() {
+        switch (shape) {
+            case 0: hipLaunchKernelGGL(kmc_read_peak_kernel<5>, dim3(n_cu), dim3(1024), 0, st, (const uint8_t*)d_buf, n16, d_out); break;      // the walk kernel's shape
+            case 1: hipLaunchKernelGGL(kmc_read_peak_kernel<8>, dim3(n_cu * 8), dim3(256), 0, st, (const uint8_t*)d_buf, n16, d_out); break;
+            case 2: hipLaunchKernelGGL(kmc_read_peak_kernel<4>, dim3(n_cu * 2), dim3(1024), 0, st, (const uint8_t*)d_buf, n16, d_out); break;
+            default: hipLaunchKernelGGL(kmc_read_peak_kernel<8>, dim3(n_cu * 4), dim3(512), 0, st, (const uint8_t*)d_buf, n16, d_out); break;
+        }
+    };
+    if (hipMalloc((void**)&d_out, sizeof(unsigned long long)) != hipSuccess) return KMC_ERR_NOMEM;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipMemsetAsync(d_out, 0, sizeof(unsigned long long), st) != hipSuccess) rc = KMC_ERR_HIP;
+    if (!rc) {
+        launch();   // warm-up (clocks, code object)
+        (void)hipEventRecord(e0, st);
+        for (int i = 0; i < iters; ++i) launch();
+        (void)hipEventRecord(e1, st);
+        if (hipGetLastError() != hipSuccess || hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess ||
+            hipMemcpy(&h, d_out, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) rc = KMC_ERR_HIP;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    (void)hipFree(d_out);
+    if (rc) return rc;
+    *ms_avg = (double)ms / iters;
+    if (xor_out) *xor_out = h;   // (iters + 1 launches: the xor of an even number of passes is 0, of an odd number the buffer's checksum)
+    return KMC_OK;
+}
+
 // ---- the ABI proper: no C++ exception leaves the library (kmc.h: "no exception or abort crosses the ABI") ----
 namespace {
 template <typename F>
@@ -2080,6 +2330,9 @@ extern "C" int kmc_merge_pairs_device(kmc_ctx* c, const void* d_key_hi, const vo
 }
 extern "C" int kmc_finalize(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total) {
     return guarded(c, [&]() -> int { return kmc_finalize_impl(c, n_distinct, n_total); });
+}
+extern "C" int kmc_finalize_async(kmc_ctx* c) {
+    return guarded(c, [&]() -> int { return kmc_finalize_async_impl(c); });
 }
 extern "C" int kmc_export(kmc_ctx* c, uint64_t* key_hi, uint64_t* key_lo, uint64_t* count, uint64_t cap) {
     return guarded(c, [&]() -> int { return kmc_export_impl(c, key_hi, key_lo, count, cap); });
@@ -2119,6 +2372,9 @@ extern "C" int kmc_count_file(kmc_ctx* c, const char* path, uint64_t* n_distinct
 }
 extern "C" int kmc_count_file_multi(kmc_ctx** ctxs, uint32_t n_ctx, const char* path, uint64_t* n_distinct, uint64_t* n_total) {
     return guarded((ctxs && n_ctx ? ctxs[0] : nullptr), [&]() -> int { return kmc_count_file_multi_impl(ctxs, n_ctx, path, n_distinct, n_total); });
+}
+extern "C" int kmc_read_peak_device(const void* d_buf, uint64_t n_bytes, int device, void* stream, int shape, int iters, double* ms_avg, uint64_t* xor_out) {
+    return guarded(nullptr, [&]() -> int { return kmc_read_peak_device_impl(d_buf, n_bytes, device, stream, shape, iters, ms_avg, xor_out); });
 }
 extern "C" int kmc_synth_reads_device(const kmc_synth* s, uint64_t first_record, uint64_t n_records, void* d_bases,
                                       void* d_offsets, int device, void* stream) {

@@ -21,6 +21,10 @@ enum { KMC_CTR_OCCUPIED = 0, KMC_CTR_SPILL = 1, KMC_CTR_ERR = 2, KMC_CTR_KMERS =
        KMC_CTR_SUM2 = 10,                   // sum of counts of a merged (table + sorted runs) view
        KMC_CTR_FASTFIN = 11,                // 1: the speculative small-table finalize produced the sorted view
        KMC_CTR_SLABSKIP = 12,               // slabs kmc_merge_slabs_kernel skipped (oversize: payload not inline)
+       // host mirror only (never device counters): what kmc_small_finalize_kernel publishes about itself
+       KMC_CTR_FINSEQ = 13,                 // sequence number of the finalize launch that wrote the mirror last
+       KMC_CTR_FINOK = 14,                  // finalize launches of this ctx that produced a view (cumulative)
+       KMC_CTR_FINSKIP = 15,                // oversize slabs seen by those launches (cumulative)
        KMC_CTR_N = 16 };
 
 // Global (HBM) open-addressing count table.  One-word keys (KW==1, k<=31) use key_lo only and

@@ -51,15 +51,33 @@ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_cnt, u64* o
     if (lane == 0 && sum) atomicAdd((unsigned long long*)&g.counters[c_sum], sum);
 }
 
-// kmc_reset in one launch: every slot empty, every counter zero
+// kmc_reset in one launch: every slot empty, every counter zero.
+// done != nullptr: the table may already BE empty (a finalize queued without waiting, kmc_finalize_async, drains it
+// when it succeeds -- the host cannot know): a table whose counters say "nothing claimed, nothing spilled" is left
+// alone.  Every workgroup must see the SAME counters, so they are cleared by the workgroup that draws the last
+// ticket of *done (zero between launches), after all have read them.
 template <int KW>
-__global__ void kmc_reset_kernel(GTable g) {
+__global__ void kmc_reset_kernel(GTable g, u32* done = nullptr) {
     const u64 cap = g.capmask + 1;
-    for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (u64)gridDim.x * blockDim.x) {
-        if (KW == 2) { g.key_hi[s] = KMC_EMPTY64; g.key_lo[s] = 0; } else g.key_lo[s] = KMC_EMPTY64;
-        g.count[s] = 0;
+    const bool skip = done && g.counters[KMC_CTR_OCCUPIED] == 0 && g.counters[KMC_CTR_SPILL] == 0;
+    if (!skip) {
+        for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (u64)gridDim.x * blockDim.x) {
+            if (KW == 2) { g.key_hi[s] = KMC_EMPTY64; g.key_lo[s] = 0; } else g.key_lo[s] = KMC_EMPTY64;
+            g.count[s] = 0;
+        }
     }
-    if (blockIdx.x == 0 && threadIdx.x < KMC_CTR_N) g.counters[threadIdx.x] = 0;
+    if (!done) {
+        if (blockIdx.x == 0 && threadIdx.x < KMC_CTR_N) g.counters[threadIdx.x] = 0;
+        return;
+    }
+    __shared__ u32 s_last;
+    __syncthreads();   // (this workgroup has read the counters)
+    if (threadIdx.x == 0) s_last = (atomicAdd(done, 1u) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {
+        if (threadIdx.x < KMC_CTR_N) g.counters[threadIdx.x] = 0;
+        if (threadIdx.x == 0) *done = 0;
+    }
 }
 
 // The table as it is before a launch whose size rests on a PREDICTION of how many new keys it brings
@@ -233,111 +251,139 @@ __global__ void kmc_merge_slabs_kernel(GTable g, const u64* __restrict__ slabs, 
 // Fast finalize for small tables (n <= KMC_OCC_LIST_CAP claimed slots, listed in g.occ_list): the GPU
 // form of the reference's final ordering step (k-mer-count/src/main.rs:87) for the common case of a
 // few thousand distinct keys, in ONE launch that uses the whole chip instead of one CU:
-//   rank sort -- keys in a table are distinct, so the sorted position of key i is the number of
-//   keys smaller than it.  Workgroup b holds 64 of the keys in LDS and adds, for EVERY key i, how
-//   many of its 64 are smaller (LDS broadcast reads, no data movement) to rank[i] with an
-//   agent-scope atomic; n*n/64 comparisons per workgroup, n/64 workgroups side by side.  The
-//   workgroup whose "done" ticket is the last one scatters (key, count) to position rank[i], sums
-//   the counts and leaves rank[] and the ticket counter zeroed for the next launch.
-// It is launched speculatively right behind the count kernels: it reads the occupancy on the device
-// and gives up (FASTFIN = 0) unless the table is small and nothing spilled, so kmc_finalize needs a
-// single host synchronisation.
+//   rank sort -- keys in a table are distinct, so the sorted position of key i is the number of keys
+//   smaller than it.  Workgroup b OWNS keys 64 b .. 64 b + 63: it brings every key of the table through
+//   LDS in tiles of 4096 (2048 two-word) keys and thread (m, s) counts how many keys of the s-th sixteenth of a tile are
+//   smaller than owned key m (all lanes of a wave read the same LDS address: a broadcast, no bank
+//   conflict); the sixteen partial ranks of a key are added up in LDS and the workgroup writes its 64
+//   (key, count) pairs to their final places.  No global atomic, no second phase.
+//   (Round 2's version turned this around -- every workgroup compared ALL keys against its 64 and added
+//   partial ranks to a global rank[] array, 177 k device-scope atomics for 3,350 keys, then the workgroup
+//   with the last ticket scattered: 20-31 us per launch, a third of the step's time outside the count kernel.)
+// It is launched speculatively right behind the count kernels: it reads the occupancy on the device and
+// gives up (FASTFIN = 0) unless the table is small, nothing spilled and the (k+16)-mer table holds no
+// pending counts, so kmc_finalize needs a single host synchronisation.
+//
+// DRAIN.  When it succeeds the sorted view holds everything the table held, so the kernel also EMPTIES the
+// table: the workgroup that draws the last ticket (all reads of the table are over by then) clears the
+// claimed slots, publishes the device counters to the host's pinned mirror (no read-back copy) and zeroes
+// them -- the table is as kmc_reset leaves it.  kmc_reset after kmc_finalize then launches nothing, and a
+// caller that goes on adding to a finalized ctx gets the view merged back first (kmc_api.hip: undrain).
 // (History: a single-workgroup bitonic network took 55-60 us for 3,350 keys whether it ran in LDS
-// with workgroup barriers, in LDS with wave-local passes, or in registers with wave shuffles --
-// stamps: 6 us gather, 39 us network, 9 us output; one CU's LDS pipe carries all the data movement.)
+// with workgroup barriers, in LDS with wave-local passes, or in registers with wave shuffles.)
 #define KMC_FIN_CHUNK 64
-#define KMC_FIN_ROUND 8   // keys per thread and round (a round = 8192 keys of the table)
+// host_mirror: the ctx's pinned mirror of [count-table counters | (k+16)-mer-table counters].  The host clears
+// mirror[KMC_CTR_FASTFIN] before the launch; 1 afterwards means: sorted view written, counters published
+// (mirror[KMC_CTR_SUM2] = sum of all counts), table drained.  The device copies of FASTFIN / SUM2 are never written.
+// ticket[0]: the ticket counter; ticket[1], ticket[2]: launches that produced a view / oversize slabs they saw, since
+// kmc_create (a caller that queues several finalizes without waiting -- kmc_finalize_async -- checks afterwards that
+// every one of them delivered); seq: this launch's number, published with everything else.
 template <int KW>
 __global__ __launch_bounds__(1024)
-void kmc_small_finalize_kernel(GTable g, u32* __restrict__ rank, u64* __restrict__ out_hi, u64* __restrict__ out_lo, u64* __restrict__ out_cnt) {
-    __shared__ u64 c_lo[KMC_FIN_CHUNK];
-    __shared__ u64 c_hi[KW == 2 ? KMC_FIN_CHUNK : 1];
+void kmc_small_finalize_kernel(GTable g, const u64* __restrict__ sk_counters, u32* __restrict__ ticket, u64* __restrict__ host_mirror, u64 seq,
+                               u64* __restrict__ out_hi, u64* __restrict__ out_lo, u64* __restrict__ out_cnt) {
+    constexpr int KMC_FIN_TILE = KW == 1 ? 4096 : 2048;   // keys of the table in LDS at a time (32 KB)
+    __shared__ u64 t_lo[KMC_FIN_TILE];
+    __shared__ u64 t_hi[KW == 2 ? KMC_FIN_TILE : 1];
+    __shared__ u32 s_rank[KMC_FIN_CHUNK];
     __shared__ u32 s_last;
     __shared__ u64 s_sum[16];
     const u32 tid = threadIdx.x;
     const u64 n = g.counters[KMC_CTR_OCCUPIED];
     const bool ok = n > 0 && n <= KMC_OCC_LIST_CAP && n <= g.occ_list_cap && n <= (u64)gridDim.x * KMC_FIN_CHUNK &&
-                    g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0;
-    if (!ok) {  // (every workgroup reads the same counters; nothing else writes them while this kernel runs)
-        if (blockIdx.x == 0 && tid == 0) { g.counters[KMC_CTR_FASTFIN] = 0; g.counters[KMC_CTR_SUM2] = 0; }
+                    g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0 &&
+                    sk_counters[KMC_CTR_OCCUPIED] == 0 && sk_counters[KMC_CTR_SPILL] == 0;
+    // (every workgroup that takes part reads these counters before it draws its ticket, and they change only
+    // behind the last ticket: all of them decide alike.  A workgroup past the table that starts that late may
+    // read zeros -- it leaves either way.)
+    if (!ok) {
+        if (blockIdx.x == 0 && tid == 0) {   // "gave up": the table is as it was
+            __hip_atomic_store(&host_mirror[KMC_CTR_FASTFIN], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_mirror[KMC_CTR_FINSEQ], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_mirror[KMC_CTR_FINOK], (u64)ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&host_mirror[KMC_CTR_FINSKIP], (u64)ticket[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     const u32 nb = (u32)((n + KMC_FIN_CHUNK - 1) / KMC_FIN_CHUNK);
     if (blockIdx.x >= nb) return;
-    // this workgroup's 64 keys (padding = all ones: never smaller than a valid key)
-    if (tid < KMC_FIN_CHUNK) {
-        const u64 j = (u64)blockIdx.x * KMC_FIN_CHUNK + tid;
-        u64 lo = ~0ull, hi = ~0ull;
-        if (j < n) {
-            const u64 slot = g.occ_list[j];
-            lo = g.key_lo[slot];
-            hi = KW == 2 ? g.key_hi[slot] : 0ull;
-        }
-        c_lo[tid] = lo;
-        if (KW == 2) c_hi[tid] = hi;
+    // my owned key: thread (m = tid & 63, seg = tid >> 6) -- every wave holds the workgroup's 64 keys, one per lane
+    const u32 m = tid & 63u, seg = tid >> 6;
+    const u64 mine_i = (u64)blockIdx.x * KMC_FIN_CHUNK + m;
+    u64 mlo = ~0ull, mhi = ~0ull, mcnt = 0;
+    if (mine_i < n) {
+        const u64 mslot = g.occ_list[mine_i];
+        mlo = g.key_lo[mslot];
+        mhi = KW == 2 ? g.key_hi[mslot] : 0ull;
+        mcnt = g.count[mslot];
     }
-    __syncthreads();
-    // every key of the table against this workgroup's 64, in rounds of 8 keys per thread (the first
-    // version held all of a table of <= 8192 keys in registers; rounds lift that limit to 32768 keys:
-    // between 8 k and 32 k keys the general sort costs 0.7 ms in launches and host round trips)
-    const u32 n_rounds = (u32)((n + 1024 * KMC_FIN_ROUND - 1) / (1024 * KMC_FIN_ROUND));
-    for (u32 rd = 0; rd < n_rounds; ++rd) {
-        u64 klo[KMC_FIN_ROUND], khi[KMC_FIN_ROUND];
-        u32 r[KMC_FIN_ROUND];
+    if (tid < KMC_FIN_CHUNK) s_rank[tid] = 0;
+    u64 sum = 0;  // (workgroup 0 also adds up all counts)
+    u32 r = 0;
+    for (u64 t0 = 0; t0 < n; t0 += KMC_FIN_TILE) {
+        const u32 tn = (u32)min((u64)KMC_FIN_TILE, n - t0);
+        __syncthreads();  // (the previous tile has been read)
 #pragma unroll
-        for (int e = 0; e < KMC_FIN_ROUND; ++e) {
-            const u64 i = ((u64)rd * KMC_FIN_ROUND + e) * 1024 + tid;
-            klo[e] = 0; khi[e] = 0; r[e] = 0;
-            if (i < n) {
-                const u64 slot = g.occ_list[i];
-                klo[e] = g.key_lo[slot];
-                if (KW == 2) khi[e] = g.key_hi[slot];
+        for (int e = 0; e < KMC_FIN_TILE / 1024; ++e) {
+            const u32 j = tid + 1024u * e;
+            if (j < tn) {
+                const u64 slot = g.occ_list[t0 + j];
+                t_lo[j] = g.key_lo[slot];
+                if (KW == 2) t_hi[j] = g.key_hi[slot];
+                if (blockIdx.x == 0) sum += g.count[slot];
             }
         }
-        for (int j = 0; j < KMC_FIN_CHUNK; ++j) {
-            const u64 cl = c_lo[j];
-            const u64 ch = KW == 2 ? c_hi[j] : 0ull;
-#pragma unroll
-            for (int e = 0; e < KMC_FIN_ROUND; ++e)
-                r[e] += (KW == 2 ? (ch < khi[e] || (ch == khi[e] && cl < klo[e])) : cl < klo[e]) ? 1u : 0u;
-        }
-#pragma unroll
-        for (int e = 0; e < KMC_FIN_ROUND; ++e) {
-            const u64 i = ((u64)rd * KMC_FIN_ROUND + e) * 1024 + tid;
-            if (i < n && r[e]) atomicAdd(&rank[i], r[e]);
+        __syncthreads();
+        // elements seg, seg + 16, ... of the tile against my key (wave-uniform addresses: LDS broadcast reads)
+        for (u32 j = seg; j < tn; j += 16) {
+            const u64 cl = t_lo[j];
+            const u64 ch = KW == 2 ? t_hi[j] : 0ull;
+            r += (KW == 2 ? (ch < mhi || (ch == mhi && cl < mlo)) : cl < mlo) ? 1u : 0u;
         }
     }
-    // every add of this workgroup has been performed before its ticket is drawn
+    if (r) atomicAdd(&s_rank[m], r);
+    // every read of the table by this workgroup has COMPLETED before its ticket is drawn (the last workgroup
+    // empties the table behind the last ticket)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) {
-        __threadfence();
-        const u32 t = atomicAdd(&rank[KMC_OCC_LIST_CAP], 1u);
-        s_last = (t == nb - 1) ? 1u : 0u;
-        if (s_last) __threadfence();
+    if (tid == 0) s_last = (atomicAdd(ticket, 1u) == nb - 1) ? 1u : 0u;
+    if (tid < KMC_FIN_CHUNK && mine_i < n) {
+        const u32 pos = s_rank[tid];
+        out_lo[pos] = mlo;
+        if (KW == 2) out_hi[pos] = mhi;
+        out_cnt[pos] = mcnt;
+    }
+    if (blockIdx.x == 0) {
+        sum = wave_sum_u64(sum);
+        if ((tid & 63) == 0) s_sum[tid >> 6] = sum;
     }
     __syncthreads();
-    if (!s_last) return;
-    // ---- the last workgroup: scatter to sorted order ----
-    u64 sum = 0;
-    for (u64 i = tid; i < n; i += 1024) {
-        const u64 slot = g.occ_list[i];
-        const u32 pos = __hip_atomic_load(&rank[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        rank[i] = 0;
-        const u64 c = g.count[slot];
-        out_lo[pos] = g.key_lo[slot];
-        if (KW == 2) out_hi[pos] = g.key_hi[slot];
-        out_cnt[pos] = c;
-        sum += c;
-    }
-    sum = wave_sum_u64(sum);
-    if ((tid & 63) == 0) s_sum[tid >> 6] = sum;
-    __syncthreads();
-    if (tid == 0) {
+    if (blockIdx.x == 0 && tid == 0) {
         u64 tot = 0;
         for (int w = 0; w < 16; ++w) tot += s_sum[w];
-        g.counters[KMC_CTR_SUM2] = tot;
-        g.counters[KMC_CTR_FASTFIN] = 1;
-        rank[KMC_OCC_LIST_CAP] = 0;
+        __hip_atomic_store(&host_mirror[KMC_CTR_SUM2], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_mirror[KMC_CTR_FASTFIN], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if (!s_last) return;
+    // ---- the last workgroup: publish the counters, empty the table (every workgroup has finished READING it) ----
+    if (tid < KMC_CTR_FINSEQ && tid != KMC_CTR_SUM2 && tid != KMC_CTR_FASTFIN)
+        __hip_atomic_store(&host_mirror[tid], g.counters[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    else if (tid == KMC_CTR_FINSEQ) {
+        const u32 okn = ticket[1] + 1u, skn = ticket[2] + (u32)g.counters[KMC_CTR_SLABSKIP];
+        ticket[1] = okn;
+        ticket[2] = skn;
+        __hip_atomic_store(&host_mirror[KMC_CTR_FINSEQ], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_mirror[KMC_CTR_FINOK], (u64)okn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_mirror[KMC_CTR_FINSKIP], (u64)skn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    else if (tid >= 64 && tid < 64 + KMC_CTR_N)
+        __hip_atomic_store(&host_mirror[KMC_CTR_N + tid - 64], sk_counters[tid - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (u64 i = tid; i < n; i += 1024) {
+        const u64 slot = g.occ_list[i];
+        if (KW == 2) { g.key_hi[slot] = KMC_EMPTY64; g.key_lo[slot] = 0; } else g.key_lo[slot] = KMC_EMPTY64;
+        g.count[slot] = 0;
+    }
+    __syncthreads();   // (the counters above have been read)
+    if (tid < KMC_CTR_N) g.counters[tid] = 0;
+    if (tid == 0) *ticket = 0;
 }

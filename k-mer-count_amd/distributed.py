@@ -188,13 +188,20 @@ def reduce_tables(local, owner, group=None, slab_entries: int = SLAB_ENTRIES, re
     skips the extra read-back of this rank's own slab header.
 
     finalize=False (both ctxs on torch's current stream): nothing here waits for the GPU -- count, pack,
-    all-gather and merge are queued and the call returns (None, None).  The caller finalizes `owner`
-    when it needs the table (e.g. once after several steps) and must then check
-    owner.stats().n_slabs_skipped: a non-zero value means some rank's table did not fit its slab and
-    that step has to be redone with finalize=True (which routes those tables through the all-to-all)."""
+    all-gather, merge and the owner's finalize (kmc_finalize_async: sorted view on the device, table drained)
+    are queued and the call returns (None, None).  Every such step still DELIVERS its sorted partition on the
+    device; what is deferred is the host's look at it.  The caller synchronises when it wants (owner.finalize()
+    returns the sizes of the last step's view) and then checks owner.stats(): n_async_ok must have grown by
+    one per step and n_async_slabs_skipped must not have grown -- otherwise some step's table did not fit its
+    slab (or the small-table path) and that step has to be redone with finalize=True (which routes such tables
+    through the all-to-all), after owner.reset(): the owner already holds the slabs that did travel inline,
+    and merging them a second time would double their counts."""
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = _dev_of(local)
+    if not finalize and dev.type == "cuda" and not (_same_stream(local, dev) and _same_stream(owner, dev)):
+        # checked BEFORE anything is queued: an error here leaves `owner` untouched
+        raise ValueError("reduce_tables(finalize=False) needs both ctxs on torch's current stream")
     words = local.slab_words(slab_entries)
     slab, gathered = _slab_buffers(words, world, dev)
     local.pack_slab_device(slab.data_ptr(), slab_entries)
@@ -203,8 +210,9 @@ def reduce_tables(local, owner, group=None, slab_entries: int = SLAB_ENTRIES, re
     _order(owner, dev, ctx_first=False)     # gathered slabs landed before the owner's stream reads them
     owner.merge_slabs_device(gathered.data_ptr(), world, slab_entries, rank, world)
     if not finalize:
-        if dev.type == "cuda" and not (_same_stream(local, dev) and _same_stream(owner, dev)):
-            raise ValueError("reduce_tables(finalize=False) needs both ctxs on torch's current stream")
+        # the owner's finalize is QUEUED (kmc_finalize_async): behind it on the stream this step's sorted, owned partition
+        # is in place on the device and the owner's table is empty again; nothing here waits for the GPU
+        owner.finalize_async()
         return None, None
     got, _ = owner.finalize()
     if local.stats().launches_last != 1:

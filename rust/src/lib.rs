@@ -43,6 +43,11 @@ pub struct KmcStats {
     pub launches_last: i32,
     pub n_slabs_skipped: u64,
     pub n_direct: u64,
+    pub kernel_ms_lifetime: f64,
+    pub launches_lifetime: u64,
+    pub n_async_ok: u64,
+    pub n_async_slabs_skipped: u64,
+    pub n_planner_stale: u64,
 }
 
 #[repr(C)]
@@ -95,6 +100,8 @@ extern "C" {
     pub fn kmc_merge_slabs_device(ctx: *mut KmcCtx, d_slabs: *const c_void, n_slabs: u32, slab_entries: u64, my_part: u32, n_parts: u32) -> c_int;
     pub fn kmc_poll(ctx: *mut KmcCtx) -> c_int;
     pub fn kmc_sync(ctx: *mut KmcCtx) -> c_int;
+    pub fn kmc_finalize_async(ctx: *mut KmcCtx) -> c_int;
+    pub fn kmc_read_peak_device(d_buf: *const c_void, n_bytes: u64, device: c_int, stream: *mut c_void, shape: c_int, iters: c_int, ms_avg: *mut f64, xor_out: *mut u64) -> c_int;
     pub fn kmc_read_pieces(read_len: u64, k: c_int, starts: *mut u64, ends: *mut u64, cap: u64) -> u64;
     pub fn kmc_forget_source(ctx: *mut KmcCtx, what: c_int) -> c_int;
     pub fn kmc_get_stats(ctx: *const KmcCtx, out: *mut KmcStats) -> c_int;

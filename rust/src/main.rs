@@ -34,12 +34,12 @@ fn main() {
         if record.is_empty() {
             break; // main.rs:60-62
         }
-        if k.is_none() {
-            // the reference aborts on anything but ACGT (main.rs:23)
-            if let Some(c) = record.seq().iter().find(|c| !b"ACGT".contains(c)) {
-                panic!("Unexpected charactor {} appears in {}", *c as char, record.id());
-            }
-        }
+        // No alphabet pre-check here: the reference panics only on a byte its bucket_sort inspects
+        // (main.rs:17-23), i.e. a byte that some emitted chunk covers.  include/kmc.h states the same rule
+        // for KMC_MODE_LR and libkmc applies it on the GPU: kmc_add_batch / kmc_finalize return
+        // KMC_ERR_ALPHABET ("Unexpected charactor ...") for exactly those bytes, which the expect() calls
+        // below turn into the reference's panic (exit code 101).  Bytes no window reads are accepted, as in
+        // the reference and in the C++ CLI (kmc_cli.cpp).
         bases.extend_from_slice(record.seq());
         offsets.push(bases.len() as u64);
     }

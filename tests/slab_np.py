@@ -88,9 +88,15 @@ class CpuCtx:
             self._pending = []
         return len(self.lo), int(np.sum(self.cnt, dtype=np.uint64))
 
+    def finalize_async(self):
+        self.finalize()
+        self._async_ok = getattr(self, "_async_ok", 0) + 1
+
     def stats(self):
         s = _Stats()
         s.n_slabs_skipped = self._skipped
+        s.n_async_ok = getattr(self, "_async_ok", 0)
+        s.n_async_slabs_skipped = self._skipped
         s.n_distinct = len(self.lo)
         s.n_kmers = int(np.sum(self.cnt, dtype=np.uint64))
         return s

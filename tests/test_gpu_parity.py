@@ -1069,3 +1069,57 @@ def test_walk_second_level_memo_kplus16_table(kmc, oracle, k, monkeypatch):
         kc.reset()
         kc.add_batch(hb, ho)          # one launch on history: the tiny table and its spill area overflow
         assert kc.export().equals(want)
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_forget_source_keeps_pending_kplus16_counts(kmc, oracle, k, monkeypatch):
+    """kmc_forget_source(KMC_FORGET_MEMO) between a WALK batch whose LDS memo overflowed and the next consumer: the
+    (k+16)-mer table holds that batch's COUNTS until the deferred unfold, so forgetting the memo has to unfold them
+    first (it used to memset them away: the table came out short, silently).  Pool of 64 lines = thousands of
+    contexts, far more than the LDS memo holds; with and without a poll in between; counts of two batches add."""
+    monkeypatch.setenv("KMC_SK_SLOTS", str(1 << 18))
+    s = kmc.Synth(seed=4242, pool=64)
+    hb, ho = kmc.synth_reads_host(s, 0, 60_000)
+    want = oracle.count_kmers(hb, ho, k, True, method=1)
+    for polled in (True, False):
+        with kmc.KmerCounter(k=k, algo=kmc.ALGO_WALK) as kc:
+            kc.add_batch(hb, ho)
+            if polled:
+                kc.poll()
+            kc.forget_source(memo=True, history=False)
+            got = kc.export()
+            assert got.equals(want), (k, polled, got.n_total, want.n_total)
+            kc.add_batch(hb, ho)                    # memo re-learned; counts of both batches
+            kc.forget_source(memo=True, history=True)
+            t = kc.export()
+            assert np.array_equal(t.key_lo, want.key_lo) and np.array_equal(t.count, want.count * 2), (k, polled)
+
+
+@pytest.mark.parametrize("k", [31, 63])
+def test_count_file_multi_high_cardinality(kmc, oracle, k, tmp_path, monkeypatch):
+    """kmc_count_file_multi on all-distinct input: every ctx's table is a sorted run (or table + run), so the
+    source ctx's kmc_finalize goes through the MERGE branch whose last kernels used to be still queued when the
+    destination's stream started its peer copies of the view.  Two and three ctxs on this one device."""
+    import subprocess
+    from conftest import ROOT
+    p = tmp_path / "rnd.fasta"
+    with open(p, "wb") as f:
+        subprocess.run([os.path.join(ROOT, "bin", "kmc-genfasta"), "--bytes", "12000000", "--seed", "11", "--pool", "0"], stdout=f, check=True)
+    fb, fo = oracle.parse_fasta(str(p))
+    want = oracle.count_kmers(fb, fo, k, True, method=1)
+    monkeypatch.setenv("KMC_INGEST_CHUNK_BYTES", "700000")
+    for n_ctx in (2, 3):
+        cs = [kmc.KmerCounter(k=k) for _ in range(n_ctx)]
+        try:
+            # a table entry next to the runs: the merge branch of kmc_finalize on every source ctx
+            for c in cs:
+                c.add_batch(fb[:800], fo[:3])
+            nd, nt = kmc.count_file_multi(cs, str(p))
+            w2 = oracle.count_kmers(np.concatenate([fb] + [fb[:800]] * n_ctx),
+                                    np.concatenate([fo] + [fo[1:3] + fo[-1] + 800 * i for i in range(n_ctx)]).astype(np.uint64), k, True, method=1)
+            assert (nd, nt) == (w2.n_distinct, w2.n_total), (k, n_ctx)
+            assert cs[0].export().equals(w2), (k, n_ctx)
+        finally:
+            for c in cs:
+                c.close()
+    assert want.n_total > 0
