@@ -1123,3 +1123,105 @@ def test_count_file_multi_high_cardinality(kmc, oracle, k, tmp_path, monkeypatch
             for c in cs:
                 c.close()
     assert want.n_total > 0
+
+
+def test_planner_randomised_batch_sequences(kmc, oracle):
+    """A fixed-seed slice of tools/stress_sort_lr.py inside the suite (the launch planner of kmc_add_batch* steers with a
+    dozen flags, two tables and a snapshot; its one real bug of round 2 was found by that tool, outside the suite):
+    sequences of batches that mix generator pools of 10 / 40 / 1000 lines and all-distinct reads in ONE ctx, with
+    finalizes in the middle (table drained into the view, then filled again), resets, polls, forgotten history, ragged
+    reads and N bytes, under all four algorithms and k in {21, 31, 47, 48, 63} -- every look at the table must equal the
+    oracle's count of everything added since the last reset, and the planner's debug invariant must hold (no risky
+    launch armed on counters older than a queued unfold / merge: kmc_stats.n_planner_stale)."""
+    rng = np.random.default_rng(20261005)
+    algos = [kmc.ALGO_AUTO, kmc.ALGO_WALK, kmc.ALGO_STREAM, kmc.ALGO_SORT]
+    n_cases = 36
+    for case in range(n_cases):
+        k = int(rng.choice([21, 31, 47, 48, 63]))
+        algo = algos[case % 4]
+        canonical = bool(rng.integers(0, 2))
+        acc_b, acc_o = [], [np.zeros(1, np.uint64)]
+
+        def want_now():
+            b = np.concatenate(acc_b) if acc_b else np.zeros(0, np.uint8)
+            o = np.concatenate(acc_o).astype(np.uint64)
+            return oracle.count_kmers(b, o, k, canonical, method=1)
+
+        with kmc.KmerCounter(k=k, canonical=canonical, algo=algo) as kc:
+            n_ops = int(rng.integers(2, 6))
+            for op in range(n_ops):
+                pool = int(rng.choice([0, 10, 40, 1000]))
+                n_rec = int(rng.integers(200, 70_000 if algo != kmc.ALGO_STREAM else 25_000))
+                s = kmc.Synth(seed=int(rng.integers(1, 1 << 30)), pool=pool)
+                hb, ho = kmc.synth_reads_host(s, int(rng.integers(0, 1000)), n_rec)
+                if rng.integers(0, 4) == 0:      # ragged reads (some shorter than k, some empty)
+                    lens = rng.integers(0, 401, size=n_rec)
+                    hb = np.concatenate([hb[int(ho[i]):int(ho[i]) + int(lens[i])] for i in range(n_rec)]) if n_rec else hb
+                    ho = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+                if rng.integers(0, 4) == 0 and hb.size:   # N bytes: windows skipped (8a-def)
+                    hb = hb.copy()
+                    hb[rng.integers(0, hb.size, size=max(1, hb.size // 4000))] = ord("N")
+                kc.add_batch(hb, ho)
+                base = acc_o[-1][-1]
+                acc_b.append(hb)
+                acc_o.append(ho[1:] + base)
+                what = int(rng.integers(0, 6))
+                if what == 0:                     # look at the table in the middle: drained into the view, filled again next op
+                    assert kc.export().equals(want_now()), ("mid", case, op, k, algo, pool, n_rec)
+                elif what == 1:
+                    kc.poll()
+                elif what == 2:
+                    kc.forget_source(memo=bool(rng.integers(0, 2)), history=True)
+                elif what == 3 and op + 1 < n_ops:  # start over
+                    kc.reset()
+                    acc_b, acc_o = [], [np.zeros(1, np.uint64)]
+            got = kc.export()
+            want = want_now()
+            assert got.equals(want), ("end", case, k, algo, canonical, got.n_distinct, want.n_distinct, got.n_total, want.n_total)
+            nd, nt = kc.finalize()                # a second finalize with nothing added: the same view
+            assert (nd, nt) == (want.n_distinct, want.n_total)
+            assert kc.stats().n_planner_stale == 0, (case, k, algo)
+
+
+def test_finalize_async_small_tables(kmc, oracle):
+    """kmc_finalize_async: the finalize of a small table is queued (sorted view on the device, table drained, counters
+    published) and the call returns; kmc_reset behind it does not wait either; the next synchronising call takes the
+    outcome from there.  Steps of count -> finalize_async -> reset deliver every time (n_async_ok), the last view is the
+    table; a table that is NOT small falls back to the synchronous finalize."""
+    s = kmc.Synth(seed=5)
+    hb, ho = kmc.synth_reads_host(s, 0, 30_000)
+    for k in (31, 63):
+        want = oracle.count_kmers(hb, ho, k, True, method=1)
+        with kmc.KmerCounter(k=k) as kc:
+            kc.add_batch(hb, ho)
+            assert kc.export().equals(want)           # (learn the source: later batches go out in one launch)
+            ok0 = kc.stats().n_async_ok
+            for step in range(6):
+                kc.reset()
+                kc.add_batch(hb, ho)
+                kc.finalize_async()
+            nd, nt = kc.finalize()                    # looks at the last queued finalize: no second sort
+            assert (nd, nt) == (want.n_distinct, want.n_total)
+            assert kc.export().equals(want)
+            st = kc.stats()
+            assert st.n_async_ok - ok0 == 6 and st.n_async_slabs_skipped == 0
+            kc.finalize_async()                       # nothing new: a no-op
+            kc.add_batch(hb, ho)                      # adding behind an unobserved finalize: the view goes back into the table
+            t = kc.export()
+            assert np.array_equal(t.key_lo, want.key_lo) and np.array_equal(t.count, want.count * 2)
+            kc.finalize_async()
+            kc.reset()                                # reset behind an unobserved finalize (drained or not: decided on the device)
+            kc.add_batch(hb, ho)
+            assert kc.export().equals(want)
+    hb0, ho0 = kmc.synth_reads_host(kmc.Synth(seed=6, pool=0), 0, 20_000)   # 7 M distinct 31-mers: not a small table
+    want0 = oracle.count_kmers(hb0, ho0, 31, True, method=1)
+    with kmc.KmerCounter(k=31) as kc:
+        kc.add_batch(hb0, ho0)
+        kc.finalize_async()
+        assert kc.export().equals(want0)
+        kc.reset()
+        kc.add_batch(hb, ho)
+        kc.add_batch(hb0, ho0)
+        kc.finalize_async()
+        both = oracle.count_kmers(np.concatenate([hb, hb0]), np.concatenate([ho, ho0[1:] + ho[-1]]).astype(np.uint64), 31, True, method=1)
+        assert kc.export().equals(both)
