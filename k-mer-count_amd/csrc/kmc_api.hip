@@ -30,6 +30,7 @@
 #include "kmc_walk.hip.h"
 #include "kmc_lr.hip.h"
 #include "kmc_msd.hip.h"
+#include "kmc_extract.hip.h"
 #include "kmc_peak.hip.h"
 #include "kmc_ingest.h"
 
@@ -89,6 +90,7 @@ struct kmc_ctx {
     bool walk_ws_clean = false;  // workspace header + dense counters are zero (left so by kmc_walk_tail_kernel)
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
     DevBuf s_lo[2], s_hi[2];
+    DevBuf a_hist, a_rand, a_ror;   // level-0 histogram rows / AND / OR words of the accumulated key ranges (kmc_extract.hip.h)
     // KMC_ALGO_SORT accumulates: a batch only EXTRACTS its keys behind those of the batches before it (s_lo[0] /
     // s_hi[0]); they are sorted into ONE run when somebody needs the result (kmc_finalize, a reduce) or when 2^31
     // positions have come together.  (Sorting batch by batch left one run per batch -- 16 for a 1 GB file read in
@@ -97,7 +99,7 @@ struct kmc_ctx {
     u64 acc_hint = 0;        // positions the caller expects in all (kmc_count_file: the file size); sizes the first allocation
     DevBuf lr_rank;  // LR mode: rank of every position's 27-mer among the batch's distinct 27-mers
     // hand-written MSD radix sort (kmc_msd.hip.h): per-range histograms, segment lists, terminals
-    DevBuf m_hist, m_stot, m_bsum, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_cnt, m_w[2];
+    DevBuf m_hist, m_stot, m_bsum, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_status, m_w[2];
     MsdCtl* h_ctl = nullptr;  // pinned mirror of the sort's device counters
     struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0, cap = 0; u64 total = 0; bool total_known = false; };
     std::vector<Run> runs;       // live runs
@@ -527,6 +529,12 @@ int poll_fin_and_settle(kmc_ctx* c) {
     return settle(c);
 }
 
+// one workgroup per KMC_FIN_CHUNK keys; the grid follows the size of the last table seen (+ 25 %), at least 64
+// workgroups.  (Workgroups past the table leave at once, but hundreds of them still cost microseconds.)  A table that
+// outgrew the grid is noticed by kmc_finalize and finalized again with the full grid.
+int small_finalize_grid(const kmc_ctx* c) {
+    return (int)std::min<u64>(KMC_OCC_LIST_CAP / KMC_FIN_CHUNK, std::max<u64>(64, (c->fin_hint + c->fin_hint / 4) / KMC_FIN_CHUNK + 8));
+}
 // The speculative small-table finalize (kmc_table.hip.h): queued behind whatever is still running.
 int launch_small_finalize(kmc_ctx* c, int grid) {
     GTable g = gtable_of(c, c->tab);
@@ -654,8 +662,8 @@ int launch_stream(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
     const bool canon = c->cfg.canonical != 0;
     { int rc = launch_begin(c); if (rc) return rc; }
 #define LAUNCH_STREAM(KWV, CAN)                                                                             \
-    hipLaunchKernelGGL((kmc_stream_kernel<KWV, CAN, 0>), dim3(grid), dim3(KMC_STREAM_THREADS), 0, c->stream, \
-                       d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, cpw, range_begin, g, (u64*)nullptr, (u64*)nullptr)
+    hipLaunchKernelGGL((kmc_stream_kernel<KWV, CAN>), dim3(grid), dim3(KMC_STREAM_THREADS), 0, c->stream, \
+                       d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, cpw, range_begin, g)
     if (c->KW == 1) { if (canon) LAUNCH_STREAM(1, true); else LAUNCH_STREAM(1, false); }
     else { if (canon) LAUNCH_STREAM(2, true); else LAUNCH_STREAM(2, false); }
 #undef LAUNCH_STREAM
@@ -665,21 +673,20 @@ int launch_stream(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
 
 // ---- KMC_ALGO_SORT -------------------------------------------------------------------------------
 
-// extraction front end: one key per base position of chunks [chunk_begin, chunk_end)
+// extraction front end (kmc_extract.hip.h): one key per base position of chunks [chunk_begin, chunk_end), padded with
+// filler to whole ranges of KMC_MSD_RANGE positions, plus each range's level-0 histogram row and AND / OR words
 int launch_extract(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases,
-                   u64 chunk_begin, u64 chunk_end, u64 range_begin, u64* out_hi, u64* out_lo) {
-    u64 n_chunks = chunk_end - chunk_begin;
-    if (!n_chunks) return KMC_OK;
-    u64 max_waves = (u64)c->n_cu * 4 * KMC_STREAM_WAVES;  // 2 workgroups per CU resident (no LDS table), 2 rounds
-    u64 cpw = (n_chunks + max_waves - 1) / max_waves;
-    if (cpw < 4) cpw = std::min<u64>(4, n_chunks);
-    u64 waves = (n_chunks + cpw - 1) / cpw;
-    int grid = (int)((waves + KMC_STREAM_WAVES - 1) / KMC_STREAM_WAVES);
-    GTable g = gtable_of(c, c->tab);
+                   u64 chunk_begin, u64 chunk_end, u64 range_begin, u32 n_ranges, u64* out_hi, u64* out_lo, u32* hist, u64* rand_, u64* ror_) {
+    if (!n_ranges) return KMC_OK;
+    const int grid = (int)std::min<u64>(n_ranges, (u64)c->n_cu);   // one 1024-thread workgroup per CU is resident (registers)
     const bool canon = c->cfg.canonical != 0;
-#define LAUNCH_EXTRACT(KWV, CAN)                                                                             \
-    hipLaunchKernelGGL((kmc_stream_kernel<KWV, CAN, 1>), dim3(grid), dim3(KMC_STREAM_THREADS), 0, c->stream, \
-                       d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, cpw, range_begin, g, out_hi, out_lo)
+#define LAUNCH_EXTRACT(KWV, CAN)                                                                                                   \
+    do {                                                                                                                           \
+        static std::atomic<unsigned long long> attr{0};                                                                            \
+        if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_extract_hist_kernel<KWV, CAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ExtractLds<KWV>)); \
+        hipLaunchKernelGGL((kmc_extract_hist_kernel<KWV, CAN>), dim3(grid), dim3(KMC_STREAM_THREADS), sizeof(ExtractLds<KWV>), c->stream,    \
+                           d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, range_begin, n_ranges, c->d_counters, out_hi, out_lo, hist, rand_, ror_); \
+    } while (0)
     if (c->KW == 1) { if (canon) LAUNCH_EXTRACT(1, true); else LAUNCH_EXTRACT(1, false); }
     else { if (canon) LAUNCH_EXTRACT(2, true); else LAUNCH_EXTRACT(2, false); }
 #undef LAUNCH_EXTRACT
@@ -694,7 +701,9 @@ int launch_extract(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64
 // of segments that go on) and one for the size of the run.
 // KW: words per key (1: lo only).  out == nullptr: the run joins c->runs; otherwise it is handed to the
 // caller (n == 0 when nothing but filler came in).
-int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w[2], u64 n, unsigned kb, int KW, kmc_ctx::Run* out = nullptr, bool repeated_keys = false) {
+// pre0: level 0's per-range histograms and AND / OR words are already in c->a_hist / a_rand / a_ror (the extraction kernel
+// computed them while it wrote the keys: kmc_extract.hip.h); n is then a multiple of KMC_MSD_RANGE.
+int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w[2], u64 n, unsigned kb, int KW, kmc_ctx::Run* out = nullptr, bool repeated_keys = false, bool pre0 = false) {
     if (out) *out = kmc_ctx::Run{};
     if (!n) return KMC_OK;
     if (n >= (1ull << 32) - KMC_MSD_RANGE) return fail(c, KMC_ERR_ARG, "msd sort: more than 2^32 keys in one pass");
@@ -727,7 +736,6 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     MSD_ENSURE(c->m_nd, term_cap * sizeof(u32));
     MSD_ENSURE(c->m_base, term_cap * sizeof(u32));
     MSD_ENSURE(c->m_ctl, sizeof(MsdCtl));
-    MSD_ENSURE(c->m_cnt, n * (weights ? sizeof(u64) : sizeof(u32)));
     MSD_ENSURE(c->m_bsum, (std::max<u64>(n_words, term_cap) / KMC_SCAN_PER_BLOCK + 2) * sizeof(u32));
 #undef MSD_ENSURE
     if (!c->h_ctl) HIPCHK(c, hipHostMalloc((void**)&c->h_ctl, sizeof(MsdCtl)));
@@ -745,22 +753,27 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
         u32* first = (u32*)c->m_first.p;
         hipLaunchKernelGGL(kmc_msd_ranges_kernel, dim3(1), dim3(1024), 0, c->stream, (const MsdSeg*)seg, n_seg, first, ctl);
         const u32 grid = (u32)std::min<u64>(n / KMC_MSD_RANGE + n_seg + 1, max_ranges);
-        if (KW == 1) hipLaunchKernelGGL(kmc_msd_hist_kernel<1>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1],
-                                        (const MsdSeg*)seg, n_seg, (const u32*)first, (int)kb, l == 0 ? 1 : 0, (u32*)c->m_hist.p, (u64*)c->m_rmin.p, (u64*)c->m_rmax.p, (const MsdCtl*)ctl);
+        const bool have = pre0 && l == 0;   // this level's histogram rows came with the keys
+        u32* const hist_l = have ? (u32*)c->a_hist.p : (u32*)c->m_hist.p;
+        u64* const rmin_l = have ? (u64*)c->a_rand.p : (u64*)c->m_rmin.p;
+        u64* const rmax_l = have ? (u64*)c->a_ror.p : (u64*)c->m_rmax.p;
+        if (have) { /* nothing to read back */ }
+        else if (KW == 1) hipLaunchKernelGGL(kmc_msd_hist_kernel<1>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1],
+                                        (const MsdSeg*)seg, n_seg, (const u32*)first, (int)kb, l == 0 ? 1 : 0, hist_l, rmin_l, rmax_l, (const MsdCtl*)ctl);
         else hipLaunchKernelGGL(kmc_msd_hist_kernel<2>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1],
-                                (const MsdSeg*)seg, n_seg, (const u32*)first, (int)kb, l == 0 ? 1 : 0, (u32*)c->m_hist.p, (u64*)c->m_rmin.p, (u64*)c->m_rmax.p, (const MsdCtl*)ctl);
+                                (const MsdSeg*)seg, n_seg, (const u32*)first, (int)kb, l == 0 ? 1 : 0, hist_l, rmin_l, rmax_l, (const MsdCtl*)ctl);
         HIPCHK(c, hipMemsetAsync(&ctl->n_next, 0, sizeof(u32), c->stream));
         const u32 S = n_seg <= 4096 ? 64u : 1u;  // few segments = long ones: digit columns spread over 64 workgroups
-        hipLaunchKernelGGL(kmc_msd_scan_a_kernel, dim3(n_seg * S), dim3(KMC_MSD_THREADS), 0, c->stream, n_seg, S, (const u32*)first, (u32*)c->m_hist.p, (u32*)c->m_stot.p);
-        hipLaunchKernelGGL(kmc_msd_scan_kernel, dim3(n_seg), dim3(KMC_MSD_ND), 0, c->stream, (const MsdSeg*)seg, n_seg, (const u32*)first, (u32*)c->m_hist.p, (const u32*)c->m_stot.p,
-                           (const u64*)c->m_rmin.p, (const u64*)c->m_rmax.p, (u32*)c->m_cbase.p, (u32*)c->m_skip.p, l == 0 ? 1 : 0, leaf_cap,
+        hipLaunchKernelGGL(kmc_msd_scan_a_kernel, dim3(n_seg * S), dim3(KMC_MSD_THREADS), 0, c->stream, n_seg, S, (const u32*)first, hist_l, (u32*)c->m_stot.p);
+        hipLaunchKernelGGL(kmc_msd_scan_kernel, dim3(n_seg), dim3(KMC_MSD_ND), 0, c->stream, (const MsdSeg*)seg, n_seg, (const u32*)first, hist_l, (const u32*)c->m_stot.p,
+                           (const u64*)rmin_l, (const u64*)rmax_l, (u32*)c->m_cbase.p, (u32*)c->m_skip.p, l == 0 ? 1 : 0, leaf_cap,
                            next, (u32)max_seg, (MsdTerm*)c->m_term.p, (u32)term_cap, (unsigned long long*)c->m_bitmap.p, ctl);
 #define MSD_SCATTER(KWV, WV)                                                                                                              \
         do {                                                                                                                              \
             static std::atomic<unsigned long long> attr{0};                                                                               \
             if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_msd_scatter_kernel<KWV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdScatterLds<KWV, WV>)); \
             hipLaunchKernelGGL((kmc_msd_scatter_kernel<KWV, WV>), dim3(grid), dim3(1024), sizeof(MsdScatterLds<KWV, WV>), c->stream, hi[0], lo[0], w[0], hi[1], lo[1], w[1], \
-                               (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)c->m_hist.p, (const u32*)c->m_cbase.p, (const u32*)c->m_skip.p, \
+                               (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)hist_l, (const u32*)c->m_cbase.p, (const u32*)c->m_skip.p, \
                                (int)kb, l == 0 ? 1 : 0, (const MsdCtl*)ctl);                                                 \
         } while (0)
         if (KW == 1) { if (weights) MSD_SCATTER(1, true); else MSD_SCATTER(1, false); }
@@ -784,48 +797,60 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     }
     hipLaunchKernelGGL(kmc_msd_order_kernel, dim3(grid_for(c, n_term, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_term.p, n_term,
                        (const unsigned long long*)c->m_bitmap.p, (const u32*)c->m_rank.p, (MsdTerm*)c->m_ord.p);
-    void* t_cnt0 = c->m_cnt.p;  // pair staging: counts, 64 bits with weights, 32 without (keys are staged in the key buffers themselves)
-#define MSD_LEAF(KWV, WV, CAPV, SCRV)                                                                                                       \
+    // the run the leaves write into: at most one pair per valid key
+    const u64 run_cap = std::max<u64>(weights ? n : std::min<u64>(n, (u64)c->h_ctl->n_valid), 1);
+    kmc_ctx::Run run;
+    rc = take_run(c, run_cap, &run);
+    if (rc) return rc;
+    rc = ensure(c, c->m_status, (size_t)n_term * sizeof(unsigned long long));
+    if (rc) { c->run_pool.push_back(run); return rc; }
+    if (hipMemsetAsync(c->m_status.p, 0, (size_t)n_term * sizeof(unsigned long long), c->stream) != hipSuccess) { c->run_pool.push_back(run); return fail(c, KMC_ERR_HIP, "msd sort: status reset failed"); }
+#define MSD_LEAF(KWV, WV, CAPV, SCRV, BASE_IN)                                                                                              \
     do {                                                                                                                                    \
         static std::atomic<unsigned long long> attr{0};                                                                                     \
         if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_msd_leaf_kernel<KWV, WV, CAPV, SCRV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdLeafLds<KWV, WV, CAPV, SCRV>)); \
         hipLaunchKernelGGL((kmc_msd_leaf_kernel<KWV, WV, CAPV, SCRV>), dim3(n_term), dim3(KMC_MSD_THREADS), sizeof(MsdLeafLds<KWV, WV, CAPV, SCRV>), c->stream, \
                            (const u64*)hi[0], (const u64*)lo[0], (const u64*)(weights ? w[0] : nullptr), (const u64*)hi[1], (const u64*)lo[1], (const u64*)(weights ? w[1] : nullptr), \
-                           (const MsdTerm*)c->m_ord.p, n_term, (int)kb, hi[0], lo[0], hi[1], lo[1], t_cnt0, (u32*)c->m_nd.p, ctl); \
+                           (const MsdTerm*)c->m_ord.p, n_term, (int)kb, hi[0], lo[0], (u64*)(weights ? w[0] : nullptr), hi[1], lo[1], (u64*)(weights ? w[1] : nullptr), \
+                           run.hi, run.lo, run.cnt, (unsigned long long*)c->m_status.p, (const u32*)(BASE_IN), (u32*)c->m_nd.p, ctl);      \
     } while (0)
     // (leaf size and wave scratch by what the keys look like: kmc_msd.hip.h, MsdLeafLds)
-    if (KW == 1) {
-        if (weights) MSD_LEAF(1, true, KMC_MSD_LEAF1, 128);
-        else if (clustered) MSD_LEAF(1, false, KMC_MSD_LEAF1, 256);
-        else MSD_LEAF(1, false, KMC_MSD_LEAF1, 2);   // (23,004 bytes of LDS: seven leaves per CU at 512-byte granules)
-    } else if (weights) MSD_LEAF(2, true, KMC_MSD_LEAF2W, 64);
-    else if (leaf_cap > 1024) MSD_LEAF(2, false, KMC_MSD_LEAF2, 16);
-    else MSD_LEAF(2, false, 1024, 128);
-#undef MSD_LEAF
-    {   // base[t] = exclusive prefix of the terminals' pair counts
+    auto launch_leaves = [&](const u32* base_in) {
+        if (KW == 1) {
+            if (weights) MSD_LEAF(1, true, KMC_MSD_LEAF1, 128, base_in);
+            else if (clustered) MSD_LEAF(1, false, KMC_MSD_LEAF1, 256, base_in);
+            else MSD_LEAF(1, false, KMC_MSD_LEAF1, 2, base_in);   // (seven leaves per CU at 512-byte granules)
+        } else if (weights) MSD_LEAF(2, true, KMC_MSD_LEAF2W, 64, base_in);
+        else if (leaf_cap > 1024) MSD_LEAF(2, false, KMC_MSD_LEAF2, 16, base_in);
+        else MSD_LEAF(2, false, 1024, 128, base_in);
+    };
+    launch_leaves(nullptr);
+    auto give_back = [&](int code, const char* what) { c->run_pool.push_back(run); return fail(c, code, "msd sort: %s", what); };
+    if (hipGetLastError() != hipSuccess) return give_back(KMC_ERR_HIP, "leaf launch failed");
+    if (hipMemcpyAsync(c->h_ctl, ctl, sizeof(MsdCtl), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+        return give_back(KMC_ERR_HIP, "leaf kernel failed");
+    if (c->h_ctl->overflow & 4u) {
+        // a leaf's bounded look-back gave up (workgroups not dispatched in order?): every leaf has left its pair count in
+        // nd[]; scan them and run the leaves once more with the bases given (no look-back)
+        c->st.n_lookback_fallbacks++;
         const u32 nb = (n_term + KMC_SCAN_PER_BLOCK - 1) / KMC_SCAN_PER_BLOCK;
         hipLaunchKernelGGL(kmc_scan_sums_kernel<0>, dim3(nb), dim3(256), 0, c->stream, (const void*)c->m_nd.p, n_term, (u32*)c->m_bsum.p);
         hipLaunchKernelGGL(kmc_scan_top_kernel, dim3(1), dim3(1024), 0, c->stream, (u32*)c->m_bsum.p, nb, &ctl->n_pairs);
         hipLaunchKernelGGL(kmc_scan_final_kernel<0>, dim3(nb), dim3(256), 0, c->stream, (const void*)c->m_nd.p, n_term, (const u32*)c->m_bsum.p, (u32*)c->m_base.p);
+        (void)hipMemsetAsync(&ctl->w_total, 0, sizeof(ctl->w_total), c->stream);
+        launch_leaves((const u32*)c->m_base.p);
+        if (hipGetLastError() != hipSuccess) return give_back(KMC_ERR_HIP, "leaf launch (fallback pass) failed");
+        if (hipMemcpyAsync(c->h_ctl, ctl, sizeof(MsdCtl), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+            return give_back(KMC_ERR_HIP, "leaf kernel (fallback pass) failed");
     }
-    HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(c->h_ctl, ctl, sizeof(MsdCtl), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+#undef MSD_LEAF
+    if (c->h_ctl->overflow & 3u) return give_back(KMC_ERR_CAPACITY, "segment / terminal list overflow");
     const u64 n_pairs = c->h_ctl->n_pairs;
-    kmc_ctx::Run run;
-    rc = take_run(c, std::max<u64>(n_pairs, 1), &run);
-    if (rc) return rc;
+    if (n_pairs > run_cap) return give_back(KMC_ERR_HIP, "more pairs than keys (internal error)");
     run.n = n_pairs;
     run.total = weights ? (u64)c->h_ctl->w_total : (u64)c->h_ctl->n_valid;  // what the run's counts sum to
     run.total_known = true;
     if (!weights && c->h_ctl->n_valid >= (1u << 20)) c->msd_dup_heavy = (u64)c->h_ctl->n_valid >= 4 * std::max<u64>(n_pairs, 1);
-#define MSD_GATHER(KWV, WV)                                                                                                                \
-    hipLaunchKernelGGL((kmc_msd_gather_kernel<KWV, WV>), dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term, \
-                       (const u32*)c->m_nd.p, (const u32*)c->m_base.p, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1], (const void*)t_cnt0, run.hi, run.lo, run.cnt)
-    if (KW == 1) { if (weights) MSD_GATHER(1, true); else MSD_GATHER(1, false); }
-    else { if (weights) MSD_GATHER(2, true); else MSD_GATHER(2, false); }
-#undef MSD_GATHER
-    if (hipGetLastError() != hipSuccess) { c->run_pool.push_back(run); return fail(c, KMC_ERR_HIP, "msd sort: gather launch failed"); }
     if (out) *out = run;
     else if (n_pairs) c->runs.push_back(run);
     else c->run_pool.push_back(run);
@@ -847,7 +872,7 @@ int flush_acc(kmc_ctx* c) {
     u64* const klo[2] = {(u64*)c->s_lo[0].p, (u64*)c->s_lo[1].p};
     u64* const kwt[2] = {nullptr, nullptr};
     c->acc_n = 0;  // (whatever happens below, these keys are not sorted twice)
-    rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen, c->KW);
+    rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen, c->KW, nullptr, false, true);
     if (rc) return rc;
     rc = launch_end(c);
     if (rc) return rc;
@@ -858,22 +883,35 @@ int flush_acc(kmc_ctx* c) {
 int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 range_begin) {
     const u64 n_chunks = (n_bases + KMC_CHUNK - 1) / KMC_CHUNK;
     const u64 SB = 1ull << 21;  // chunks per sort (2^31 positions: the run kernels index with u32)
+    const u64 CPR = KMC_MSD_RANGE / KMC_CHUNK;   // chunks per range of the sort
     for (u64 cb = range_begin / KMC_CHUNK; cb < n_chunks; cb += SB) {
         const u64 ce = std::min(n_chunks, cb + SB);
-        const u64 n = (ce - cb) * KMC_CHUNK;
+        // (every batch's keys start on a range boundary of the accumulated array: its last range is padded with filler)
+        const u64 n_ranges = (ce - cb + CPR - 1) / CPR;
+        const u64 n = n_ranges * KMC_MSD_RANGE;
         if (c->acc_n + n > SB * KMC_CHUNK) { int rc = flush_acc(c); if (rc) return rc; }
         // room behind the keys already there (sized by the caller's hint the first time)
-        const u64 want = std::max<u64>(c->acc_n + n, std::min<u64>(c->acc_hint, SB * KMC_CHUNK));
+        const u64 want = std::max<u64>(c->acc_n + n, std::min<u64>(c->acc_hint + KMC_MSD_RANGE, SB * KMC_CHUNK));
         int rc = ensure_keep(c, c->s_lo[0], (size_t)(c->s_lo[0].bytes >= (c->acc_n + n) * sizeof(u64) ? (c->acc_n + n) : want) * sizeof(u64), (size_t)c->acc_n * sizeof(u64));
         if (rc) return rc;
         if (c->KW == 2) {
             rc = ensure_keep(c, c->s_hi[0], (size_t)(c->s_hi[0].bytes >= (c->acc_n + n) * sizeof(u64) ? (c->acc_n + n) : want) * sizeof(u64), (size_t)c->acc_n * sizeof(u64));
             if (rc) return rc;
         }
+        // the level-0 histogram rows and AND / OR words of the accumulated ranges
+        const u64 r0 = c->acc_n / KMC_MSD_RANGE, r_have = r0 + n_ranges, r_want = std::max<u64>(r_have, want / KMC_MSD_RANGE + 1);
+        const size_t row = (size_t)KMC_MSD_NB * sizeof(u32);
+        rc = ensure_keep(c, c->a_hist, (c->a_hist.bytes >= r_have * row ? r_have : r_want) * row, (size_t)r0 * row);
+        if (rc) return rc;
+        rc = ensure_keep(c, c->a_rand, (c->a_rand.bytes >= r_have * 16 ? r_have : r_want) * 16, (size_t)r0 * 16);
+        if (rc) return rc;
+        rc = ensure_keep(c, c->a_ror, (c->a_ror.bytes >= r_have * 16 ? r_have : r_want) * 16, (size_t)r0 * 16);
+        if (rc) return rc;
         rc = launch_begin(c);  // (this event pair brackets the extraction; the sort has its own at the flush)
         if (rc) return rc;
-        rc = launch_extract(c, d_bases, d_offsets, n_reads, n_bases, cb, ce, range_begin,
-                            c->KW == 2 ? (u64*)c->s_hi[0].p + c->acc_n : nullptr, (u64*)c->s_lo[0].p + c->acc_n);
+        rc = launch_extract(c, d_bases, d_offsets, n_reads, n_bases, cb, ce, range_begin, (u32)n_ranges,
+                            c->KW == 2 ? (u64*)c->s_hi[0].p + c->acc_n : nullptr, (u64*)c->s_lo[0].p + c->acc_n,
+                            (u32*)c->a_hist.p + (size_t)r0 * KMC_MSD_NB, (u64*)c->a_rand.p + 2 * r0, (u64*)c->a_ror.p + 2 * r0);
         if (rc) return rc;
         rc = launch_end(c);
         if (rc) return rc;
@@ -964,6 +1002,7 @@ int recover_overflow(kmc_ctx* c) {
     if (r.d_from) HIPCHK(c, hipMemcpyAsync(&from, r.d_from, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));  // (ctr[] and `from` are stack memory)
     memcpy(c->h_counters, ctr, sizeof(ctr));
+    c->polled_epoch = c->table_epoch;   // (the table is what the snapshot says)
     c->h_counters[KMC_CTR_OCCUPIED] = r.ctr[KMC_CTR_OCCUPIED];
     c->direct_seen = ctr[KMC_CTR_BADBASE];
     c->kmers_seen = ctr[KMC_CTR_KMERS];
@@ -993,6 +1032,7 @@ int drop_batch_from_table(kmc_ctx* c, const u64* ctr0) {
     c->sk_dirty = false;
     HIPCHK(c, hipStreamSynchronize(c->stream));  // (ctr0 is the caller's stack memory)
     memcpy(c->h_counters, ctr0, KMC_CTR_N * sizeof(u64));
+    c->polled_epoch = c->table_epoch;
     c->direct_seen = ctr0[KMC_CTR_BADBASE];
     c->kmers_seen = ctr0[KMC_CTR_KMERS];
     c->risky.armed = false;
@@ -1427,9 +1467,9 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     if (c->spill_cnt) (void)hipFree(c->spill_cnt);
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
                       &c->t_idx0, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo, &c->vr_reads, &c->vr_cnt, &c->vr_pos,
-                      &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->lr_rank,
+                      &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->lr_rank, &c->a_hist, &c->a_rand, &c->a_ror,
                       &c->m_hist, &c->m_stot, &c->m_bsum, &c->m_rmin, &c->m_rmax, &c->m_seg[0], &c->m_seg[1], &c->m_first, &c->m_cbase, &c->m_skip, &c->m_term, &c->m_ord,
-                      &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_cnt, &c->m_w[0], &c->m_w[1],
+                      &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_status, &c->m_w[0], &c->m_w[1],
                       &c->snap_hi, &c->snap_lo, &c->snap_cnt, &c->snap_n, &c->snap_occ, &c->rx_hi, &c->rx_lo, &c->rx_cnt};
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     sk_free(c);
@@ -1526,6 +1566,7 @@ static int kmc_reset_impl(kmc_ctx* c) {
     }
     memset(c->h_counters, 0, KMC_CTR_N * sizeof(u64));
     c->pending = false;
+    c->polled_epoch = c->table_epoch;   // (an empty table is a known state)
     c->sorted_valid = false;
     c->n_sorted = 0;
     free_runs(c, false);
@@ -1543,6 +1584,7 @@ static int kmc_reset_impl(kmc_ctx* c) {
     c->st.n_planner_stale = keep.n_planner_stale;
     c->st.n_async_ok = keep.n_async_ok;
     c->st.n_async_slabs_skipped = keep.n_async_slabs_skipped;
+    c->st.n_lookback_fallbacks = keep.n_lookback_fallbacks;
     return KMC_OK;
 }
 
@@ -1631,10 +1673,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         rc = ensure(c, c->o_lo, fb); if (rc) return rc;
         rc = ensure(c, c->o_cnt, fb); if (rc) return rc;
         if (c->KW == 2) { rc = ensure(c, c->o_hi, fb); if (rc) return rc; }
-        // one workgroup per 64 keys; the grid follows the size of the last table seen (x2), at least 128
-        // workgroups: 512 workgroups of which 460 leave at once cost 3 us more than 128 on the benchmark's
-        // 3,350 keys.  A table that outgrew the grid is noticed below and finalized again with the full grid.
-        fgrid_used = (int)std::min<u64>(KMC_OCC_LIST_CAP / KMC_FIN_CHUNK, std::max<u64>(128, next_pow2(2 * c->fin_hint / KMC_FIN_CHUNK + 1)));
+        fgrid_used = small_finalize_grid(c);
         rc = launch_small_finalize(c, fgrid_used);
         if (rc) return rc;
         tried_fast = true;
@@ -1766,8 +1805,7 @@ static int kmc_finalize_async_impl(kmc_ctx* c) {
     rc = ensure(c, c->o_cnt, fb); if (rc) return rc;
     if (c->KW == 2) { rc = ensure(c, c->o_hi, fb); if (rc) return rc; }
     if (c->sk_dirty) { rc = flush_sk(c); if (rc) return rc; }
-    const int grid = (int)std::min<u64>(KMC_OCC_LIST_CAP / KMC_FIN_CHUNK, std::max<u64>(128, next_pow2(2 * c->fin_hint / KMC_FIN_CHUNK + 1)));
-    rc = launch_small_finalize(c, grid);
+    rc = launch_small_finalize(c, small_finalize_grid(c));
     if (rc) return rc;
     c->async_fin = true;
     c->sorted_valid = false;   // (until somebody has looked)

@@ -15,9 +15,12 @@
 // per-wave 64-word LDS bitmap; windows that cross a read start or contain a non-ACGT byte are
 // masked with a shift-OR smear of those bits.
 //
-// Accumulation.  Each workgroup owns an LDS open-addressing partial histogram (ds_cmpst claim,
-// ds_add count); keys that do not fit go straight to the global table with device-scope
-// atomics; at the end the LDS table is flushed with one global atomic per distinct key.
+// Accumulation.  Each workgroup owns an LDS partial histogram of FORWARD-strand keys in buckets of two slots
+// (StreamLds below): the hot path reads a key's two home slots and adds on a hit, with no loop and no CAS;
+// first sights and keys that do not fit their home bucket go through a per-wave miss buffer and a probing
+// insert once per chunk; what fits nowhere goes to the global table with device-scope atomics; at the end
+// the LDS table is flushed with one global atomic per distinct key, the canonical strand chosen there.
+// (The extraction front end of KMC_ALGO_SORT, which shares this file's window helpers, is kmc_extract.hip.h.)
 #pragma once
 #include "kmc_device.hip.h"
 
@@ -204,12 +207,6 @@ __device__ __forceinline__ WMask<KW> smear(WMask<KW> m, int t) {
     return m;
 }
 
-// LDS of the extract-only variant (SINK == 1): just the per-wave read-start bitmaps
-struct StreamLdsLite {
-    u32 sbits[KMC_STREAM_WAVES][64];
-    u32 tr[KMC_STREAM_WAVES][32 * 16];   // half a wave's keys, 32 bits at a time, on their way to coalesced stores
-};
-
 // A wave holds 16 consecutive keys per lane (lane l: positions 16 l .. 16 l + 15 of its 1024-position chunk);
 // stored as they are, one store instruction touches 64 lines of 128 B with 8 B each.  Transposed through LDS
 // (rows of 32 lanes, 32 bits at a time, column index rotated by the row: two-way conflicts writing, none
@@ -242,30 +239,21 @@ __device__ __forceinline__ void stream_store_transposed(u32* tr, int lane, const
 #pragma unroll
     for (int i = 0; i < 16; ++i) out[i * 64 + lane] = ((u64)hi32[i] << 32) | lo32[i];
 }
-template <int KW, int SINK> struct StreamLdsSel { typedef StreamLds<KW> type; };
-template <int KW> struct StreamLdsSel<KW, 1> { typedef StreamLdsLite type; };
-
-// SINK == 0: count into the LDS / global tables (KMC_ALGO_STREAM).
-// SINK == 1: extraction only (front end of KMC_ALGO_SORT): write ONE key per base position of the
-//            launch's chunk range to out_lo/out_hi -- the k-mer ending there, or all-ones where no
-//            valid window ends -- 16 consecutive keys per lane, fully coalesced, no atomics.
-template <int KW, bool CANON, int SINK>
+// Count the windows ending in chunks [chunk_begin, chunk_end) into the LDS / global tables (KMC_ALGO_STREAM).
+template <int KW, bool CANON>
 __global__ __launch_bounds__(KMC_STREAM_THREADS)
 void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets,
-                       u64 n_reads, int k, u64 chunk_begin, u64 chunk_end, u64 chunks_per_wave, u64 range_begin, GTable g,
-                       u64* __restrict__ out_hi, u64* __restrict__ out_lo) {
+                       u64 n_reads, int k, u64 chunk_begin, u64 chunk_end, u64 chunks_per_wave, u64 range_begin, GTable g) {
     constexpr int NW = 2 * KW + 1;  // window words: own + 2*KW preceding lanes
-    __shared__ typename StreamLdsSel<KW, SINK>::type L;
+    __shared__ StreamLds<KW> L;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
 
-    if constexpr (SINK == 0) {
-        for (int s = tid; s < StreamLds<KW>::LCAP; s += KMC_STREAM_THREADS) {
-            if constexpr (KW == 1) L.slot[s].lo = KMC_EMPTY64; else { L.slot[s].hi = KMC_EMPTY64; L.slot[s].lo = 0; }
-            L.cnt[s] = 0;
-        }
-        if (tid == 0) L.nfill = 0;
-        __syncthreads();
+    for (int s = tid; s < StreamLds<KW>::LCAP; s += KMC_STREAM_THREADS) {
+        if constexpr (KW == 1) L.slot[s].lo = KMC_EMPTY64; else { L.slot[s].hi = KMC_EMPTY64; L.slot[s].lo = 0; }
+        L.cnt[s] = 0;
     }
+    if (tid == 0) L.nfill = 0;
+    __syncthreads();
     u32 nbuf = 0;  // fill of this wave's miss buffer (wave-uniform)
 
     const u64 gw = (u64)blockIdx.x * KMC_STREAM_WAVES + wv;
@@ -280,9 +268,6 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
         const int kb = 2 * k;
         const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
         const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
-        // rc pre-shift: P = 32*NW - 30 - 2k
-        const int P = 32 * NW - 30 - kb;
-        const int Pq = P >> 5, Pr = P & 31;
 
         const u64 cfirst = c0 > 0 ? c0 - 1 : 0;  // warm-up chunk supplies the halo of chunk c0
         // first read-start >= first position (binary search, wave-uniform)
@@ -370,31 +355,7 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                     inv16 |= nskip >= 16 ? 0xFFFFu : ((1u << (u32)nskip) - 1u);
                 }
                 {  // (no per-lane skip of lanes without a valid window: the drain inside needs the whole wave)
-                    // rc stream words from the LSB end: Yw[m] = rc word of lane-(NW-1-m)
-                    constexpr bool RC = CANON && SINK == 1;  // SINK == 0 counts forward keys; the flush picks the strand
-                    u32 Yp[NW + 1];
-                    if (RC) {
-                        u32 Yw[2 * NW + 1];
-#pragma unroll
-                        for (int m = 0; m < NW; ++m) Yw[m] = rc_word_be(X[NW - 1 - m]);
-#pragma unroll
-                        for (int m = NW; m < 2 * NW + 1; ++m) Yw[m] = 0;
-#pragma unroll
-                        for (int m = 0; m < NW; ++m) {
-                            u32 r = 0;
-#pragma unroll
-                            for (int q = 0; q < NW; ++q)
-                                if (q == Pq) r = alignbit(Yw[m + q + 1], Yw[m + q], Pr);
-                            Yp[m] = r;
-                        }
-                        Yp[NW] = 0;
-                    }
-                    // (SINK == 1) the wave's 1024 keys of this chunk start at the position of lane 0's first key
-                    u64* const o_lo = SINK == 1 ? out_lo + (pp - 16ull * (u64)lane - chunk_begin * KMC_CHUNK) : nullptr;
-                    u64* const o_hi = (SINK == 1 && KW == 2) ? out_hi + (pp - 16ull * (u64)lane - chunk_begin * KMC_CHUNK) : nullptr;
-                    // (two-word keys: the low words leave transposed, the high words by direct stores -- both words in
-                    //  registers, 64 of them, made the kernel slower: 7.5 -> 9.1 ms)
-                    u64 vlo[SINK == 1 ? 16 : 1];
+                    // forward keys are counted; the flush picks the strand
                     u32 missmask = 0;  // bit j: this lane's window j missed both home slots
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
@@ -402,28 +363,13 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         u32 f[2 * KW];
 #pragma unroll
                         for (int m = 0; m < 2 * KW; ++m) f[m] = alignbit(X[m + 1], X[m], s);
-                        u64 flo = ((u64)f[1] << 32 | f[0]) & mask_lo, fhi = 0;
+                        const u64 flo = ((u64)f[1] << 32 | f[0]) & mask_lo;
+                        u64 fhi = 0;
                         if constexpr (KW == 2) fhi = ((u64)f[3] << 32 | f[2]) & mask_hi;
-                        u64 klo = flo, khi = fhi;
-                        if (RC) {
-                            u32 r[2 * KW];
-#pragma unroll
-                            for (int m = 0; m < 2 * KW; ++m) r[m] = alignbit(Yp[m + 1], Yp[m], 2 * j);
-                            u64 rlo = ((u64)r[1] << 32 | r[0]) & mask_lo, rhi = 0;
-                            if constexpr (KW == 2) rhi = ((u64)r[3] << 32 | r[2]) & mask_hi;
-                            if (key_less(rhi, rlo, fhi, flo)) { klo = rlo; khi = rhi; }
-                        }
                         const bool ok = !((inv16 >> j) & 1);
-                        if constexpr (SINK == 0) {
-                            missmask |= stream_probe<KW>(L, khi, klo, ok) ? (1u << j) : 0u;
-                        } else {
-                            vlo[j] = ok ? klo : ~0ull;
-                            if constexpr (KW == 2) o_hi[16 * lane + j] = ok ? khi : ~0ull;
-                            nk += ok;
-                        }
+                        missmask |= stream_probe<KW>(L, fhi, flo, ok) ? (1u << j) : 0u;
                     }
-                    if constexpr (SINK == 1) stream_store_transposed(L.tr[wv], lane, vlo, o_lo);
-                    if constexpr (SINK == 0) {
+                    {
                         nk += (u32)__popc(~inv16 & 0xFFFFu);
                         // the chunk's misses (first sight of a key, keys that did not fit their home bucket):
                         // one per lane and round into the wave's miss buffer; the drain inserts them
@@ -452,24 +398,20 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
             pw = wbe;
             pzb = zb;
         }
-        if constexpr (SINK == 0) {
-            if (nbuf) { nglobal += stream_drain<KW, CANON>(L, g, wv, lane, nbuf, k); nbuf = 0; }
-        }
+        if (nbuf) { nglobal += stream_drain<KW, CANON>(L, g, wv, lane, nbuf, k); nbuf = 0; }
     }
     nk = wave_sum_u64(nk);
     nglobal = wave_sum_u64(nglobal);
     if (lane == 0 && nk) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_KMERS], nk);
     if (lane == 0 && nglobal) atomicAdd((unsigned long long*)&g.counters[KMC_CTR_BADBASE], nglobal);  // "direct" k-mers
 
-    if constexpr (SINK == 0) {
-        __syncthreads();
-        for (int s = tid; s < StreamLds<KW>::LCAP; s += KMC_STREAM_THREADS) {
-            const u32 c = L.cnt[s];
-            if (c) {
-                u64 hi = 0;
-                if constexpr (KW == 2) hi = L.slot[s].hi;
-                stream_gadd<KW, CANON>(g, hi, L.slot[s].lo, k, c);
-            }
+    __syncthreads();
+    for (int s = tid; s < StreamLds<KW>::LCAP; s += KMC_STREAM_THREADS) {
+        const u32 c = L.cnt[s];
+        if (c) {
+            u64 hi = 0;
+            if constexpr (KW == 2) hi = L.slot[s].hi;
+            stream_gadd<KW, CANON>(g, hi, L.slot[s].lo, k, c);
         }
     }
 }

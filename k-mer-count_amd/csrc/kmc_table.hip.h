@@ -252,11 +252,12 @@ __global__ void kmc_merge_slabs_kernel(GTable g, const u64* __restrict__ slabs, 
 // form of the reference's final ordering step (k-mer-count/src/main.rs:87) for the common case of a
 // few thousand distinct keys, in ONE launch that uses the whole chip instead of one CU:
 //   rank sort -- keys in a table are distinct, so the sorted position of key i is the number of keys
-//   smaller than it.  Workgroup b OWNS keys 64 b .. 64 b + 63: it brings every key of the table through
-//   LDS in tiles of 4096 (2048 two-word) keys and thread (m, s) counts how many keys of the s-th sixteenth of a tile are
-//   smaller than owned key m (all lanes of a wave read the same LDS address: a broadcast, no bank
-//   conflict); the sixteen partial ranks of a key are added up in LDS and the workgroup writes its 64
-//   (key, count) pairs to their final places.  No global atomic, no second phase.
+//   smaller than it.  Workgroup b OWNS keys 16 b .. 16 b + 15: it brings every key of the table through
+//   LDS in tiles of 4096 (2048 two-word) keys and thread (m, s) counts how many of the tile's keys s, s + 64, ...
+//   are smaller than owned key m (the 16 lanes of a quarter wave read the same LDS address: broadcasts, no bank
+//   conflict: 52 compares per thread for the benchmark's 3,350 keys, 210 workgroups side by side); the 64 partial
+//   ranks of a key are added up by shuffles + LDS and the workgroup writes its 16 (key, count) pairs to their
+//   final places.  No global atomic, no second phase.
 //   (Round 2's version turned this around -- every workgroup compared ALL keys against its 64 and added
 //   partial ranks to a global rank[] array, 177 k device-scope atomics for 3,350 keys, then the workgroup
 //   with the last ticket scattered: 20-31 us per launch, a third of the step's time outside the count kernel.)
@@ -271,7 +272,7 @@ __global__ void kmc_merge_slabs_kernel(GTable g, const u64* __restrict__ slabs, 
 // caller that goes on adding to a finalized ctx gets the view merged back first (kmc_api.hip: undrain).
 // (History: a single-workgroup bitonic network took 55-60 us for 3,350 keys whether it ran in LDS
 // with workgroup barriers, in LDS with wave-local passes, or in registers with wave shuffles.)
-#define KMC_FIN_CHUNK 64
+#define KMC_FIN_CHUNK 16
 // host_mirror: the ctx's pinned mirror of [count-table counters | (k+16)-mer-table counters].  The host clears
 // mirror[KMC_CTR_FASTFIN] before the launch; 1 afterwards means: sorted view written, counters published
 // (mirror[KMC_CTR_SUM2] = sum of all counts), table drained.  The device copies of FASTFIN / SUM2 are never written.
@@ -307,8 +308,9 @@ void kmc_small_finalize_kernel(GTable g, const u64* __restrict__ sk_counters, u3
     }
     const u32 nb = (u32)((n + KMC_FIN_CHUNK - 1) / KMC_FIN_CHUNK);
     if (blockIdx.x >= nb) return;
-    // my owned key: thread (m = tid & 63, seg = tid >> 6) -- every wave holds the workgroup's 64 keys, one per lane
-    const u32 m = tid & 63u, seg = tid >> 6;
+    // my owned key: thread (m = tid & 15, seg = tid >> 4) -- every quarter wave holds the workgroup's 16 keys, one per lane
+    const u32 m = tid & (KMC_FIN_CHUNK - 1u), seg = tid / KMC_FIN_CHUNK;
+    constexpr u32 NSEG = 1024 / KMC_FIN_CHUNK;
     const u64 mine_i = (u64)blockIdx.x * KMC_FIN_CHUNK + m;
     u64 mlo = ~0ull, mhi = ~0ull, mcnt = 0;
     if (mine_i < n) {
@@ -334,14 +336,25 @@ void kmc_small_finalize_kernel(GTable g, const u64* __restrict__ sk_counters, u3
             }
         }
         __syncthreads();
-        // elements seg, seg + 16, ... of the tile against my key (wave-uniform addresses: LDS broadcast reads)
-        for (u32 j = seg; j < tn; j += 16) {
+        // elements seg, seg + 64, ... of the tile against my key (one address per quarter wave: LDS broadcast reads);
+        // four independent reads per trip, so that the loop does not pay an LDS round trip per element
+        u32 j = seg;
+        for (; j + 3 * NSEG < tn; j += 4 * NSEG) {
+            u64 cl[4], ch[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { cl[u] = t_lo[j + u * NSEG]; ch[u] = KW == 2 ? t_hi[j + u * NSEG] : 0ull; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r += (KW == 2 ? (ch[u] < mhi || (ch[u] == mhi && cl[u] < mlo)) : cl[u] < mlo) ? 1u : 0u;
+        }
+        for (; j < tn; j += NSEG) {
             const u64 cl = t_lo[j];
             const u64 ch = KW == 2 ? t_hi[j] : 0ull;
             r += (KW == 2 ? (ch < mhi || (ch == mhi && cl < mlo)) : cl < mlo) ? 1u : 0u;
         }
     }
-    if (r) atomicAdd(&s_rank[m], r);
+    r += __shfl_xor(r, 16);   // the four segments of a wave
+    r += __shfl_xor(r, 32);
+    if ((tid & 63u) < KMC_FIN_CHUNK && r) atomicAdd(&s_rank[m], r);
     // every read of the table by this workgroup has COMPLETED before its ticket is drawn (the last workgroup
     // empties the table behind the last ticket)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
