@@ -114,8 +114,6 @@ typedef struct kmc_stats {
     uint64_t launches_lifetime;   /* resets the ctx per step reads the kernel time of all steps once, after the last) */
     uint64_t n_async_ok;          /* finalizes of this ctx that produced their view through the small-table kernel, and the oversize */
     uint64_t n_async_slabs_skipped; /* slabs they saw, both since kmc_create (as of the last call that synchronised): see kmc_finalize_async */
-    uint64_t n_lookback_fallbacks; /* sorts whose leaves could not learn their output place from their predecessors in time and were run
-                                      a second time with scanned bases (kmc_msd.hip.h; expected 0; since kmc_create) */
     uint64_t n_planner_stale;     /* debug invariant of the launch planner: risky launches whose table snapshot was armed on
                                      counters older than the last queued unfold / merge (must stay 0) */
 } kmc_stats;

@@ -53,8 +53,7 @@ class Stats(C.Structure):
                 ("kernel_ms_last", C.c_double), ("kernel_ms_total", C.c_double), ("algo_last", C.c_int32),
                 ("launches_last", C.c_int32), ("n_slabs_skipped", C.c_uint64), ("n_direct", C.c_uint64),
                 ("kernel_ms_lifetime", C.c_double), ("launches_lifetime", C.c_uint64),
-                ("n_async_ok", C.c_uint64), ("n_async_slabs_skipped", C.c_uint64), ("n_lookback_fallbacks", C.c_uint64),
-                ("n_planner_stale", C.c_uint64)]
+                ("n_async_ok", C.c_uint64), ("n_async_slabs_skipped", C.c_uint64), ("n_planner_stale", C.c_uint64)]
 
 
 class _Reads(C.Structure):

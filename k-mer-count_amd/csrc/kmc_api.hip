@@ -99,7 +99,7 @@ struct kmc_ctx {
     u64 acc_hint = 0;        // positions the caller expects in all (kmc_count_file: the file size); sizes the first allocation
     DevBuf lr_rank;  // LR mode: rank of every position's 27-mer among the batch's distinct 27-mers
     // hand-written MSD radix sort (kmc_msd.hip.h): per-range histograms, segment lists, terminals
-    DevBuf m_hist, m_stot, m_bsum, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_status, m_w[2];
+    DevBuf m_hist, m_stot, m_bsum, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_w[2];
     MsdCtl* h_ctl = nullptr;  // pinned mirror of the sort's device counters
     struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0, cap = 0; u64 total = 0; bool total_known = false; };
     std::vector<Run> runs;       // live runs
@@ -112,7 +112,11 @@ struct kmc_ctx {
     // hipEvent pairs bracketing every count-kernel launch, batch by batch: a batch's events are read once they have
     // completed (harvest_timing), possibly several batches later -- a caller that never synchronises this ctx (the
     // multi-GPU step: count, pack, reset) still gets every batch's kernel time into kernel_ms_lifetime
-    std::deque<std::vector<hipEvent_t>> tb;   // batches whose events have not been read yet (front = oldest)
+    struct TimedBatch { std::vector<hipEvent_t> ev; int algo = 0; u64 n_bases = 0; };
+    std::deque<TimedBatch> tb;                // batches whose events have not been read yet (front = oldest)
+    // KMC_ALGO_AUTO chooses by MEASURED cost: kernel milliseconds per base of this ctx's recent walk-path batches (walk
+    // kernel + (k+16)-mer unfold + the table merge at finalize) and sort-path batches (< 0: not measured yet)
+    double walk_ms_per_base = -1.0, sort_ms_per_base = -1.0;
     std::vector<hipEvent_t> ev_free;          // events to reuse
     kmc_stats st{};
     int fin_parity = 0;    // which OUT/SUM counter pair the next kmc_finalize uses
@@ -518,6 +522,8 @@ int settle(kmc_ctx* c) {
     return fail(c, KMC_ERR_CAPACITY, "table growth did not converge");
 }
 
+int launch_begin(kmc_ctx* c);
+int launch_end(kmc_ctx* c);
 int poll_and_settle(kmc_ctx* c) {
     int rc = poll(c);
     if (rc) return rc;
@@ -607,8 +613,12 @@ int flush_sk(kmc_ctx* c) {
         int r = grow_to(c, next_pow2((occ0 + 16 * sk_known) * 2));
         if (r) return r;
     }
-    int r = kmc_sk_unfold_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, sk_table_of(c), gtable_of(c, c->tab));
+    int r = launch_begin(c);   // (the unfold is part of what the walk path costs: kernel_ms_*, KMC_ALGO_AUTO's comparison)
+    if (r) return r;
+    r = kmc_sk_unfold_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, sk_table_of(c), gtable_of(c, c->tab));
     if (r) return fail(c, r, "(k+16)-mer unfold launch failed");
+    r = launch_end(c);
+    if (r) return r;
     c->sk_dirty = false;
     c->pending = true;
     c->table_epoch++;
@@ -632,17 +642,17 @@ int take_event(kmc_ctx* c, hipEvent_t* e) {
 }
 int launch_begin(kmc_ctx* c) {
     if (c->tb.empty()) c->tb.emplace_back();
-    if (c->tb.back().size() & 1) { c->ev_free.push_back(c->tb.back().back()); c->tb.back().pop_back(); }   // (a bracket left open by a failed launch)
+    if (c->tb.back().ev.size() & 1) { c->ev_free.push_back(c->tb.back().ev.back()); c->tb.back().ev.pop_back(); }   // (a bracket left open by a failed launch)
     hipEvent_t e;
     { int rc = take_event(c, &e); if (rc) return rc; }
-    c->tb.back().push_back(e);
+    c->tb.back().ev.push_back(e);
     HIPCHK(c, hipEventRecord(e, c->stream));
     return KMC_OK;
 }
 int launch_end(kmc_ctx* c) {
     hipEvent_t e;
     { int rc = take_event(c, &e); if (rc) return rc; }
-    c->tb.back().push_back(e);
+    c->tb.back().ev.push_back(e);
     HIPCHK(c, hipEventRecord(e, c->stream));
     c->batch_pending = true;
     return KMC_OK;
@@ -802,50 +812,51 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     kmc_ctx::Run run;
     rc = take_run(c, run_cap, &run);
     if (rc) return rc;
-    rc = ensure(c, c->m_status, (size_t)n_term * sizeof(unsigned long long));
-    if (rc) { c->run_pool.push_back(run); return rc; }
-    if (hipMemsetAsync(c->m_status.p, 0, (size_t)n_term * sizeof(unsigned long long), c->stream) != hipSuccess) { c->run_pool.push_back(run); return fail(c, KMC_ERR_HIP, "msd sort: status reset failed"); }
-#define MSD_LEAF(KWV, WV, CAPV, SCRV, BASE_IN)                                                                                              \
+#define MSD_LEAF(KWV, WV, CAPV, SCRV)                                                                                                       \
     do {                                                                                                                                    \
         static std::atomic<unsigned long long> attr{0};                                                                                     \
         if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_msd_leaf_kernel<KWV, WV, CAPV, SCRV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdLeafLds<KWV, WV, CAPV, SCRV>)); \
         hipLaunchKernelGGL((kmc_msd_leaf_kernel<KWV, WV, CAPV, SCRV>), dim3(n_term), dim3(KMC_MSD_THREADS), sizeof(MsdLeafLds<KWV, WV, CAPV, SCRV>), c->stream, \
                            (const u64*)hi[0], (const u64*)lo[0], (const u64*)(weights ? w[0] : nullptr), (const u64*)hi[1], (const u64*)lo[1], (const u64*)(weights ? w[1] : nullptr), \
                            (const MsdTerm*)c->m_ord.p, n_term, (int)kb, hi[0], lo[0], (u64*)(weights ? w[0] : nullptr), hi[1], lo[1], (u64*)(weights ? w[1] : nullptr), \
-                           run.hi, run.lo, run.cnt, (unsigned long long*)c->m_status.p, (const u32*)(BASE_IN), (u32*)c->m_nd.p, ctl);      \
+                           run.hi, run.lo, run.cnt, (u32*)c->m_nd.p, ctl);                                                                  \
     } while (0)
     // (leaf size and wave scratch by what the keys look like: kmc_msd.hip.h, MsdLeafLds)
-    auto launch_leaves = [&](const u32* base_in) {
-        if (KW == 1) {
-            if (weights) MSD_LEAF(1, true, KMC_MSD_LEAF1, 128, base_in);
-            else if (clustered) MSD_LEAF(1, false, KMC_MSD_LEAF1, 256, base_in);
-            else MSD_LEAF(1, false, KMC_MSD_LEAF1, 2, base_in);   // (seven leaves per CU at 512-byte granules)
-        } else if (weights) MSD_LEAF(2, true, KMC_MSD_LEAF2W, 64, base_in);
-        else if (leaf_cap > 1024) MSD_LEAF(2, false, KMC_MSD_LEAF2, 16, base_in);
-        else MSD_LEAF(2, false, 1024, 128, base_in);
-    };
-    launch_leaves(nullptr);
+    if (KW == 1) {
+        if (weights) MSD_LEAF(1, true, KMC_MSD_LEAF1, 128);
+        else if (clustered) MSD_LEAF(1, false, KMC_MSD_LEAF1, 256);
+        else MSD_LEAF(1, false, KMC_MSD_LEAF1, 2);   // (seven leaves per CU at 512-byte granules)
+    } else if (weights) MSD_LEAF(2, true, KMC_MSD_LEAF2W, 64);
+    else if (leaf_cap > 1024) MSD_LEAF(2, false, KMC_MSD_LEAF2, 16);
+    else MSD_LEAF(2, false, 1024, 128);
+#undef MSD_LEAF
     auto give_back = [&](int code, const char* what) { c->run_pool.push_back(run); return fail(c, code, "msd sort: %s", what); };
     if (hipGetLastError() != hipSuccess) return give_back(KMC_ERR_HIP, "leaf launch failed");
     if (hipMemcpyAsync(c->h_ctl, ctl, sizeof(MsdCtl), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
         return give_back(KMC_ERR_HIP, "leaf kernel failed");
-    if (c->h_ctl->overflow & 4u) {
-        // a leaf's bounded look-back gave up (workgroups not dispatched in order?): every leaf has left its pair count in
-        // nd[]; scan them and run the leaves once more with the bases given (no look-back)
-        c->st.n_lookback_fallbacks++;
+    if (c->h_ctl->overflow) return give_back(KMC_ERR_CAPACITY, "segment / terminal list overflow");
+    const u64 n_keys_in = (u64)c->h_ctl->n_valid;
+    u64 n_dups = 0;
+    for (u32 d : c->h_ctl->n_dups) n_dups += d;
+    const u64 n_pairs = n_keys_in - std::min<u64>(n_keys_in, n_dups);
+    if (n_dups) {
+        // some keys repeat: the run has holes behind the terminals that hold them -- scan the pair counts, move the pairs
+        // together into a run of the right size (work proportional to the distinct keys), give the sparse one back
+        kmc_ctx::Run dense;
+        rc = take_run(c, std::max<u64>(n_pairs, 1), &dense);
+        if (rc) { c->run_pool.push_back(run); return rc; }
         const u32 nb = (n_term + KMC_SCAN_PER_BLOCK - 1) / KMC_SCAN_PER_BLOCK;
         hipLaunchKernelGGL(kmc_scan_sums_kernel<0>, dim3(nb), dim3(256), 0, c->stream, (const void*)c->m_nd.p, n_term, (u32*)c->m_bsum.p);
         hipLaunchKernelGGL(kmc_scan_top_kernel, dim3(1), dim3(1024), 0, c->stream, (u32*)c->m_bsum.p, nb, &ctl->n_pairs);
         hipLaunchKernelGGL(kmc_scan_final_kernel<0>, dim3(nb), dim3(256), 0, c->stream, (const void*)c->m_nd.p, n_term, (const u32*)c->m_bsum.p, (u32*)c->m_base.p);
-        (void)hipMemsetAsync(&ctl->w_total, 0, sizeof(ctl->w_total), c->stream);
-        launch_leaves((const u32*)c->m_base.p);
-        if (hipGetLastError() != hipSuccess) return give_back(KMC_ERR_HIP, "leaf launch (fallback pass) failed");
-        if (hipMemcpyAsync(c->h_ctl, ctl, sizeof(MsdCtl), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
-            return give_back(KMC_ERR_HIP, "leaf kernel (fallback pass) failed");
+        if (KW == 1) hipLaunchKernelGGL(kmc_msd_gather_kernel<1>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term,
+                                        (const u32*)c->m_nd.p, (const u32*)c->m_base.p, (const u64*)run.hi, (const u64*)run.lo, (const u64*)run.cnt, dense.hi, dense.lo, dense.cnt);
+        else hipLaunchKernelGGL(kmc_msd_gather_kernel<2>, dim3(grid_for(c, (u64)n_term * 64, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_ord.p, n_term,
+                                (const u32*)c->m_nd.p, (const u32*)c->m_base.p, (const u64*)run.hi, (const u64*)run.lo, (const u64*)run.cnt, dense.hi, dense.lo, dense.cnt);
+        c->run_pool.push_back(run);   // (stream order: the gather is queued before anything can reuse it)
+        run = dense;
+        if (hipGetLastError() != hipSuccess) return give_back(KMC_ERR_HIP, "gather launch failed");
     }
-#undef MSD_LEAF
-    if (c->h_ctl->overflow & 3u) return give_back(KMC_ERR_CAPACITY, "segment / terminal list overflow");
-    const u64 n_pairs = c->h_ctl->n_pairs;
     if (n_pairs > run_cap) return give_back(KMC_ERR_HIP, "more pairs than keys (internal error)");
     run.n = n_pairs;
     run.total = weights ? (u64)c->h_ctl->w_total : (u64)c->h_ctl->n_valid;  // what the run's counts sum to
@@ -1074,6 +1085,10 @@ int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
 }
 
 void harvest_timing(kmc_ctx* c);
+// kernel milliseconds per base of the sort path on all-distinct reads (1 GB FASTA = 0.914 G bases; profiles/r03_sort_*):
+// the prior of KMC_ALGO_AUTO's cost comparison until the ctx has sorted something itself
+#define KMC_SORT_MS_PER_BASE_1 2.9e-8
+#define KMC_SORT_MS_PER_BASE_2 5.0e-8
 int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len) {
     { int rc = resolve_async(c); if (rc) return rc; }
     { int rc = undrain(c); if (rc) return rc; }
@@ -1104,6 +1119,12 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
 
     int algo = c->cfg.algo;
     if (c->cfg.mode == KMC_MODE_LR) algo = KMC_ALGO_STREAM;  // LR runs its own kernel (kmc_lr.hip.h)
+    if (algo == KMC_ALGO_AUTO && !c->prefer_sort && c->walk_ms_per_base > 0) {
+        // by measured cost: the walk path (memo overflow: (k+16)-mer table updates, unfold, table merge) against what sorting
+        // costs on this GPU -- this ctx's own measurement when it has one, else the rate of all-distinct reads
+        const double sort_est = c->sort_ms_per_base > 0 ? c->sort_ms_per_base : (c->KW == 1 ? KMC_SORT_MS_PER_BASE_1 : KMC_SORT_MS_PER_BASE_2);
+        if (c->walk_ms_per_base > 1.1 * sort_est) c->prefer_sort = true;
+    }
     if (algo == KMC_ALGO_AUTO && c->prefer_sort) algo = KMC_ALGO_SORT;
     if (algo == KMC_ALGO_AUTO || algo == KMC_ALGO_WALK) {
         if (!max_read_len) {
@@ -1124,7 +1145,9 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
 
     harvest_timing(c);       // (batches that have finished since; never waits)
     c->tb.emplace_back();    // this batch's launch events
+    c->tb.back().n_bases = n_bases;
     int rc = KMC_OK;
+    bool batch_mixed = false;   // the batch changed path in the middle: not a rate sample of either
     {
         // Sub-batches.  A launch over n k-mers can add at most n new keys, so without history the
         // first launch is sized to what the table and spill area absorb for certain and later ones
@@ -1351,6 +1374,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                         }
                         stream_from = pos;
                         run_sort = true;
+                        batch_mixed = true;
                         c->prefer_sort = true;
                         c->st.algo_last = KMC_ALGO_SORT;
                         break;
@@ -1381,6 +1405,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                         // global atomics anyway: per-occurrence hashing is the wrong tool
                         stream_from = done * KMC_CHUNK;
                         run_sort = true;
+                        batch_mixed = true;
                         c->prefer_sort = true;
                         c->st.algo_last = KMC_ALGO_SORT;
                         break;
@@ -1396,6 +1421,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
         c->b_rho_max = batch_rho_max;  // the last launch's share is folded in by the next poll()
         c->b_open = true;
     }
+    if (!c->tb.empty()) c->tb.back().algo = ((batch_mixed || c->recovered) ? 0 : c->st.algo_last);
     return KMC_OK;
 }
 
@@ -1403,7 +1429,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
 // are not kernel time).  Only once the batch has finished on the GPU.
 void harvest_timing(kmc_ctx* c) {
     while (!c->tb.empty()) {
-        std::vector<hipEvent_t>& b = c->tb.front();
+        std::vector<hipEvent_t>& b = c->tb.front().ev;
         const bool current = c->tb.size() == 1;   // (the newest batch may still be queueing launches: leave it until it is complete AND idle)
         if (b.size() >= 2 && (b.size() & 1) == 0) {
             hipError_t q = hipEventQuery(b.back());
@@ -1419,6 +1445,13 @@ void harvest_timing(kmc_ctx* c) {
             c->st.kernel_ms_lifetime += sum;
             c->st.launches_last = (int32_t)(b.size() / 2);  // launches in that batch
             c->st.launches_lifetime += b.size() / 2;
+            // what this data source costs on the path it took (KMC_ALGO_AUTO's choice between the walk and the sort path)
+            const kmc_ctx::TimedBatch& tbk = c->tb.front();
+            if (tbk.n_bases >= (1u << 24)) {   // (small batches are launch overhead, not a rate)
+                const double per = sum / (double)tbk.n_bases;
+                double* dst = tbk.algo == KMC_ALGO_WALK ? &c->walk_ms_per_base : (tbk.algo == KMC_ALGO_SORT ? &c->sort_ms_per_base : nullptr);
+                if (dst) *dst = *dst < 0 ? per : 0.5 * (*dst + per);
+            }
         } else if (!b.empty() && current) {
             return;   // (an odd number: a launch is being bracketed right now)
         }
@@ -1469,13 +1502,13 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
                       &c->t_idx0, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo, &c->vr_reads, &c->vr_cnt, &c->vr_pos,
                       &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->lr_rank, &c->a_hist, &c->a_rand, &c->a_ror,
                       &c->m_hist, &c->m_stot, &c->m_bsum, &c->m_rmin, &c->m_rmax, &c->m_seg[0], &c->m_seg[1], &c->m_first, &c->m_cbase, &c->m_skip, &c->m_term, &c->m_ord,
-                      &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_status, &c->m_w[0], &c->m_w[1],
+                      &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_w[0], &c->m_w[1],
                       &c->snap_hi, &c->snap_lo, &c->snap_cnt, &c->snap_n, &c->snap_occ, &c->rx_hi, &c->rx_lo, &c->rx_cnt};
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     sk_free(c);
     try { free_runs(c, true); } catch (...) { /* (only the pool bookkeeping can throw; the buffers it could not list leak with the process) */ }
     for (DevBuf* b : bufs) free_buf(*b);
-    for (auto& b : c->tb) for (hipEvent_t e : b) (void)hipEventDestroy(e);
+    for (auto& b : c->tb) for (hipEvent_t e : b.ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_free) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1584,7 +1617,6 @@ static int kmc_reset_impl(kmc_ctx* c) {
     c->st.n_planner_stale = keep.n_planner_stale;
     c->st.n_async_ok = keep.n_async_ok;
     c->st.n_async_slabs_skipped = keep.n_async_slabs_skipped;
-    c->st.n_lookback_fallbacks = keep.n_lookback_fallbacks;
     return KMC_OK;
 }
 
@@ -1765,7 +1797,11 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         u64* const klo[2] = {(u64*)c->t_lo.p, (u64*)c->o_lo.p};
         u64* const kwt[2] = {(u64*)c->t_cnt.p, (u64*)c->o_cnt.p};
         const size_t before = c->runs.size();
+        rc = launch_begin(c);   // (the merge is part of what the path that left a large table costs)
+        if (rc) return rc;
         rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)c->klen, c->KW);
+        if (rc) return rc;
+        rc = launch_end(c);
         if (rc) return rc;
         // The merged view is read by other streams right after this call (kmc_export_device consumers, the
         // peer copies of kmc_count_file_multi on the destination ctx's stream): unlike the fast and single-run
@@ -1996,6 +2032,7 @@ static int kmc_forget_source_impl(kmc_ctx* c, int what) {
         c->rho_hist = -1.0;
         c->rho_last = c->rho_max = 0.0;
         c->prefer_sort = false;
+        c->walk_ms_per_base = c->sort_ms_per_base = -1.0;
         c->msd_dup_heavy = false;
         c->walk_overflowed = false;
     }

@@ -21,9 +21,9 @@
 //   leaves    one workgroup per terminal segment: an LDS pass into 512 sub-buckets of the leaf's own key range,
 //             every key then counts the smaller keys of its sub-bucket (three or four keys; sub-buckets of more
 //             than 32 keys are split again and rank-sorted by a wave), then run-length: (key, count) pairs.
-//   output    the terminals are ordered by position with a bitmap + popcount scan; a leaf learns where its pairs
-//             go from its predecessors (decoupled look-back over one status word per terminal) and writes them
-//             straight into the dense sorted run -- no staging, no gather pass.
+//   output    the terminals are ordered by position with a bitmap + popcount scan; a leaf writes its pairs into the
+//             run at its own positions, which IS the dense sorted run when no key repeats; otherwise the pair counts
+//             are scanned and the pairs gathered (work proportional to the distinct keys).
 //
 // Invalid positions (all-ones filler from the extraction kernel) fall into a 1025th bucket at level 0
 // and are dropped.  Keys may carry a 64-bit weight (an existing count): the run-length then sums
@@ -70,10 +70,12 @@ struct MsdCtl {
     u32 n_valid;     // keys that are not filler (written at level 0)
     u32 n_ranges;    // ranges of the current level (written by kmc_msd_ranges_kernel)
     u32 overflow;    // a list ran out of room (host checks)
-    u32 n_pairs;     // total (key, count) pairs (written by the last terminal's leaf, or by the terminal scan of the fallback pass)
+    u32 n_pairs;     // total (key, count) pairs (written by the terminal scan, when one is needed)
     u32 scan_total;  // total of the last kmc_scan_* call
     u32 pad;
     unsigned long long w_total;  // sum of all weights (weighted sorts: the merged table's total count)
+    u32 n_dups[64];  // keys that repeat an earlier key of their terminal (terminal t adds to slot t % 64: one word would
+                     // take 400 k same-address atomics on heavily repeated keys): pairs = valid keys - their sum
 };
 
 template <int KW>
@@ -551,70 +553,17 @@ __global__ void kmc_msd_order_kernel(const MsdTerm* __restrict__ term, u32 n_ter
 
 // ---- leaves ------------------------------------------------------------------------------------
 // One workgroup per terminal (in position order).  Result: the terminal's (key, count) pairs, sorted, written
-// straight to their final place in the dense run o_*: pair r of terminal t goes to base(t) + r, where base(t) is
-// the number of pairs of all terminals before t.  base(t) comes from a DECOUPLED LOOK-BACK: status[t] (zero before
-// the launch) is one 8-byte word {flag, count}, stored and polled with agent-scope (sc1) accesses only -- flag 1: the
-// terminal's own pair count, flag 2: the inclusive prefix.  A leaf publishes its count, wave 0 looks at the 64
-// predecessors at a time (sum the counts back to the nearest inclusive prefix; wait while a predecessor inside the
-// window has not published), publishes its inclusive prefix, and the workgroup writes.  Workgroups are dispatched
-// in blockIdx order, so a predecessor is never behind an unscheduled workgroup; should that ever not hold, the
-// bounded wait gives up, raises ctl->overflow bit 4 (every later leaf then skips its look-back) and the host runs
-// the kernel once more with bases scanned from nd[] (base_in != nullptr: no look-back at all).  nd[t] = the
-// terminal's pair count, always.  (Round 2 staged the pairs in the dead key buffer and a gather kernel made the run
-// dense: 5.1 ms of 28 per GB of all-distinct reads for a pure copy.)
-#define KMC_MSD_LB_FLAG_AGG (1ull << 62)
-#define KMC_MSD_LB_FLAG_INC (2ull << 62)
-#define KMC_MSD_LB_VALUE(v) ((u32)(v))
-// wave 0 of a leaf: base of terminal t (all 64 lanes take part; the result is wave-uniform); false: gave up
-__device__ __forceinline__ bool msd_lookback(unsigned long long* __restrict__ status, u32 t, u32 mine, MsdCtl* __restrict__ ctl, u32 lane, u32& base_out) {
-    if (t == 0) {
-        if (lane == 0) __hip_atomic_store(&status[0], KMC_MSD_LB_FLAG_INC | (unsigned long long)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        base_out = 0;
-        return true;
-    }
-    if (lane == 0) __hip_atomic_store(&status[t], KMC_MSD_LB_FLAG_AGG | (unsigned long long)mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    u32 base = 0;
-    u32 hi_t = t;         // the window covers terminals hi_t - 1, hi_t - 2, ... (lane i: hi_t - 1 - i)
-    u32 spins = 0;
-    for (;;) {
-        const bool in = lane < hi_t;
-        unsigned long long v = 0;
-        if (in) v = __hip_atomic_load(&status[hi_t - 1 - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u32 flag = (u32)(v >> 62);
-        const unsigned long long m_inc = __builtin_amdgcn_ballot_w64(in && flag == 2u);
-        const unsigned long long m_none = __builtin_amdgcn_ballot_w64(in && flag == 0u);
-        const u32 first_inc = m_inc ? (u32)__builtin_ctzll(m_inc) : 64u;
-        const u32 first_none = m_none ? (u32)__builtin_ctzll(m_none) : 64u;
-        const u32 n_in = hi_t < 64u ? hi_t : 64u;
-        if (first_inc < first_none) {          // counts of lanes 0 .. first_inc - 1 + the inclusive prefix of lane first_inc
-            u32 x = lane <= first_inc ? KMC_MSD_LB_VALUE(v) : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-            base += x;
-            break;
-        }
-        if (first_none >= n_in) {              // a window of counts only: take them all, look further back
-            u32 x = in ? KMC_MSD_LB_VALUE(v) : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-            base += x;
-            hi_t -= n_in;   // (hi_t == 0 cannot happen: terminal 0 publishes an inclusive prefix)
-            continue;
-        }
-        // a predecessor inside the window has not published yet: wait (bounded)
-        __builtin_amdgcn_s_sleep(8);
-        if ((++spins & 255u) == 0u) {
-            const u32 ov = __hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if ((ov & 4u) || spins > (1u << 22)) {
-                if (lane == 0) atomicOr(&ctl->overflow, 4u);
-                return false;
-            }
-        }
-    }
-    if (lane == 0) __hip_atomic_store(&status[t], KMC_MSD_LB_FLAG_INC | (unsigned long long)(base + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    base_out = base;
-    return true;
-}
+// straight into the run o_* at the terminal's OWN position: pair r of terminal t goes to T.begin + r.  The terminals
+// tile the valid positions, so when no key occurs twice -- reads that are really all distinct: the input the sort
+// path exists for -- the run is dense as it stands and nothing else touches it (round 2 staged every pair in the dead
+// key buffer and a gather kernel made the run dense: 5.1 ms of 28 per GB of all-distinct reads for a pure copy).  Every
+// terminal with duplicates adds their number to ctl->n_dups; if that is not zero the host scans nd[] (nd[t] = the
+// terminal's pair count, always written) and kmc_msd_gather_kernel moves the pairs together -- work proportional to the
+// DISTINCT keys, little when keys repeat a lot (LR mode, table merges), a full copy only in between.
+// (Measured and dropped: a decoupled look-back over one status word per terminal, so that every leaf writes to its
+// final dense place at once.  Exact, but 11.7 instead of 7.9 ms per GB: a leaf finishes together with the ~1,800 leaves
+// in flight around it, so the nearest inclusive prefix is a thousand terminals back and every workgroup ends up
+// waiting for the slowest of its neighbours -- profiles/r03_sort_leaf_variants.txt.)
 template <int KW, bool WEIGHTS, int CAPV, int SCRV> struct MsdLeafLds {
     static constexpr int CAP = CAPV;   // leaf capacity (KMC_MSD_LEAF1 / LEAF2 / LEAF2W; two-word sorts also run with 1024)
     // ONE image of the leaf (the keys come in through registers: with a second image a one-word leaf took
@@ -640,8 +589,6 @@ template <int KW, bool WEIGHTS, int CAPV, int SCRV> struct MsdLeafLds {
     u32 wsum[4];
     u32 bad;                  // a sub-bucket was too large for the in-wave rank sort
     u32 n_out;
-    u32 base;                 // where this terminal's pairs start in the run (look-back result)
-    u32 write_ok;             // 0: the look-back gave up (the host runs the fallback pass)
     u64 sx[4][2], sy[4][2];
 };
 
@@ -653,7 +600,6 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
                          u64* __restrict__ s_hi0, u64* __restrict__ s_lo0, u64* __restrict__ s_w0,
                          u64* __restrict__ s_hi1, u64* __restrict__ s_lo1, u64* __restrict__ s_w1,
                          u64* __restrict__ o_hi, u64* __restrict__ o_lo, u64* __restrict__ o_cnt,
-                         unsigned long long* __restrict__ status, const u32* __restrict__ base_in,
                          u32* __restrict__ nd, MsdCtl* __restrict__ ctl) {
     extern __shared__ __align__(16) unsigned char msd_smem[];
     MsdLeafLds<KW, WEIGHTS, CAPV, SCRV>& L = *reinterpret_cast<MsdLeafLds<KW, WEIGHTS, CAPV, SCRV>*>(msd_smem);
@@ -667,23 +613,17 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     u64* const t_hi = T.parity ? s_hi0 : s_hi1;
     u64* const t_w = T.parity ? s_w0 : s_w1;
     const u32 n = T.len;
-    // where this terminal's n_mine pairs start in the run: given (fallback pass) or by look-back; wave 0 calls, all of its lanes
-    auto pairs_base = [&](u32 n_mine, u32& base) -> bool {
-        if (lane == 0) nd[t] = n_mine;
-        bool ok = true;
-        if (base_in) base = base_in[t];
-        else if (__hip_atomic_load(&ctl->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 4u) ok = false;   // (some leaf gave up: count only)
-        else ok = msd_lookback(status, t, n_mine, ctl, lane, base);
-        if (ok && lane == 0 && t == n_term - 1) ctl->n_pairs = base + n_mine;
-        return ok;
+    // a terminal's n_mine pairs go to its own positions of the run; what it holds fewer pairs than keys is recorded
+    auto account = [&](u32 n_mine) {   // (one lane)
+        nd[t] = n_mine;
+        if (n_mine != n) atomicAdd(&ctl->n_dups[t & 63u], n - n_mine);
     };
-    // a terminal that is ONE pair (all keys equal): key, count; wave 0 writes
+    // a terminal that is ONE pair (all keys equal): key, count
     auto single_pair = [&](u64 hi, u64 lo, u64 cnt, u32 n_mine) {
-        if (wv == 0) {
-            u32 base = 0;
-            const bool ok = pairs_base(n_mine, base);
-            if (ok && lane == 0 && n_mine) {
-                o_lo[base] = lo; if (KW == 2) o_hi[base] = hi; o_cnt[base] = cnt;
+        if (tid == 0) {
+            account(n_mine);
+            if (n_mine) {
+                o_lo[T.begin] = lo; if (KW == 2) o_hi[T.begin] = hi; o_cnt[T.begin] = cnt;
                 if (WEIGHTS) atomicAdd(&ctl->w_total, (unsigned long long)cnt);
             }
         }
@@ -817,6 +757,33 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     //     The keys are still in their owners' registers, so the sorted image is written over b in place.  (Round 2
     //     let every THREAD insertion-sort its sub-buckets: data-dependent nested loops, 2.06 G scalar wave-instructions
     //     of exec-mask bookkeeping next to 2.47 G vector ones per GB of reads -- here the only divergence is the trip count.)
+#ifdef KMC_EXP_INSERTION
+    for (int e = 0; e < PER; ++e) rp[e] = ~0u;
+    for (u32 d = tid * (KMC_MSD_LEAF_NSB / KMC_MSD_THREADS); d < (tid + 1) * (KMC_MSD_LEAF_NSB / KMC_MSD_THREADS); ++d) {
+        const u32 o = L.off[d], m = L.off[d + 1] - o;
+        if (m > 1 && m <= KMC_MSD_THREAD_SORT) {
+            for (u32 i = 1; i < m; ++i) {
+                const u64 lo = L.b_lo[o + i], hi = KW == 2 ? L.b_hi[o + i] : 0ull;
+                u64 w = 0;
+                if (WEIGHTS) w = L.b_w[o + i];
+                u32 j = i;
+                while (j > 0) {
+                    const u64 pl = L.b_lo[o + j - 1], ph = KW == 2 ? L.b_hi[o + j - 1] : 0ull;
+                    if (!key_less(hi, lo, ph, pl)) break;
+                    L.b_lo[o + j] = pl;
+                    if (KW == 2) L.b_hi[o + j] = ph;
+                    if (WEIGHTS) L.b_w[o + j] = L.b_w[o + j - 1];
+                    --j;
+                }
+                if (j != i) {
+                    L.b_lo[o + j] = lo;
+                    if (KW == 2) L.b_hi[o + j] = hi;
+                    if (WEIGHTS) L.b_w[o + j] = w;
+                }
+            }
+        }
+    }
+#else
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
         if (tid + KMC_MSD_THREADS * e < n) {
@@ -836,6 +803,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             }
         } else rp[e] = ~0u;
     }
+#endif
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
@@ -1074,15 +1042,9 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         __syncthreads();
     }
     const u32 n_out = L.n_out;
-    // 5. where the pairs go (look-back, by wave 0), then out: straight into the run
-    if (wv == 0) {
-        u32 base = 0;
-        const bool ok = pairs_base(n_out, base);
-        if (lane == 0) { L.base = base; L.write_ok = ok ? 1u : 0u; }
-    }
-    __syncthreads();
-    if (!L.write_ok) return;   // (the host repeats the launch with scanned bases)
-    const u32 base = L.base;
+    // 5. out: straight into the run, at the terminal's own positions
+    if (tid == 0) account(n_out);
+    const u32 base = T.begin;
     u64 wtot = 0;
     for (u32 r = tid; r < n_out; r += KMC_MSD_THREADS) {
         const u32 i = hidx[r], iend = r + 1 < n_out ? hidx[r + 1] : n;
@@ -1096,5 +1058,22 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     if (WEIGHTS) {
         wtot = wave_sum_u64(wtot);
         if (lane == 0 && wtot) atomicAdd(&ctl->w_total, (unsigned long long)wtot);
+    }
+}
+
+// dense run: terminal t's nd[t] pairs move from its own positions of the sparse run (s_*) to base[t] of the dense one
+template <int KW>
+__global__ void kmc_msd_gather_kernel(const MsdTerm* __restrict__ term, u32 n_term, const u32* __restrict__ nd, const u32* __restrict__ base,
+                                      const u64* __restrict__ s_hi, const u64* __restrict__ s_lo, const u64* __restrict__ s_cnt,
+                                      u64* __restrict__ o_hi, u64* __restrict__ o_lo, u64* __restrict__ o_cnt) {
+    // one wave per terminal
+    const u32 wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63, n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (u32 t = wave; t < n_term; t += n_waves) {
+        const u32 src = term[t].begin, dst = base[t], m = nd[t];
+        for (u32 i = lane; i < m; i += 64) {
+            o_lo[dst + i] = s_lo[src + i];
+            if (KW == 2) o_hi[dst + i] = s_hi[src + i];
+            o_cnt[dst + i] = s_cnt[src + i];
+        }
     }
 }

@@ -47,7 +47,6 @@ pub struct KmcStats {
     pub launches_lifetime: u64,
     pub n_async_ok: u64,
     pub n_async_slabs_skipped: u64,
-    pub n_lookback_fallbacks: u64,
     pub n_planner_stale: u64,
 }
 
