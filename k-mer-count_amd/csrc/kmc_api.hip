@@ -686,7 +686,7 @@ int launch_stream(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
 // extraction front end (kmc_extract.hip.h): one key per base position of chunks [chunk_begin, chunk_end), padded with
 // filler to whole ranges of KMC_MSD_RANGE positions, plus each range's level-0 histogram row and AND / OR words
 int launch_extract(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases,
-                   u64 chunk_begin, u64 chunk_end, u64 range_begin, u32 n_ranges, u64* out_hi, u64* out_lo, u32* hist, u64* rand_, u64* ror_) {
+                   u64 chunk_begin, u64 chunk_end, u64 range_begin, u32 n_ranges, u64* out_hi, u64* out_lo, u32* hist, u32 hist_r0, u64* rand_, u64* ror_) {
     if (!n_ranges) return KMC_OK;
     const int grid = (int)std::min<u64>(n_ranges, (u64)c->n_cu);   // one 1024-thread workgroup per CU is resident (registers)
     const bool canon = c->cfg.canonical != 0;
@@ -695,7 +695,7 @@ int launch_extract(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64
         static std::atomic<unsigned long long> attr{0};                                                                            \
         if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_extract_hist_kernel<KWV, CAN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(ExtractLds<KWV>)); \
         hipLaunchKernelGGL((kmc_extract_hist_kernel<KWV, CAN>), dim3(grid), dim3(KMC_STREAM_THREADS), sizeof(ExtractLds<KWV>), c->stream,    \
-                           d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, range_begin, n_ranges, c->d_counters, out_hi, out_lo, hist, rand_, ror_); \
+                           d_bases, n_bases, d_offsets, n_reads, c->cfg.k, chunk_begin, chunk_end, range_begin, n_ranges, c->d_counters, out_hi, out_lo, hist, hist_r0, rand_, ror_); \
     } while (0)
     if (c->KW == 1) { if (canon) LAUNCH_EXTRACT(1, true); else LAUNCH_EXTRACT(1, false); }
     else { if (canon) LAUNCH_EXTRACT(2, true); else LAUNCH_EXTRACT(2, false); }
@@ -730,7 +730,7 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     const u64 n_words = (n + 63) / 64;
     int rc;
 #define MSD_ENSURE(buf, bytes) do { rc = ensure(c, (buf), (size_t)(bytes)); if (rc) return rc; } while (0)
-    MSD_ENSURE(c->m_hist, max_ranges * KMC_MSD_NB * sizeof(u32));
+    MSD_ENSURE(c->m_hist, msd_hist_words(max_ranges) * sizeof(u32));
     MSD_ENSURE(c->m_rmin, max_ranges * 2 * sizeof(u64));
     MSD_ENSURE(c->m_rmax, max_ranges * 2 * sizeof(u64));
     MSD_ENSURE(c->m_seg[0], max_seg * sizeof(MsdSeg));
@@ -911,8 +911,8 @@ int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
         }
         // the level-0 histogram rows and AND / OR words of the accumulated ranges
         const u64 r0 = c->acc_n / KMC_MSD_RANGE, r_have = r0 + n_ranges, r_want = std::max<u64>(r_have, want / KMC_MSD_RANGE + 1);
-        const size_t row = (size_t)KMC_MSD_NB * sizeof(u32);
-        rc = ensure_keep(c, c->a_hist, (c->a_hist.bytes >= r_have * row ? r_have : r_want) * row, (size_t)r0 * row);
+        const size_t hb_have = msd_hist_words(r_have) * sizeof(u32), hb_want = msd_hist_words(r_want) * sizeof(u32);
+        rc = ensure_keep(c, c->a_hist, c->a_hist.bytes >= hb_have ? hb_have : hb_want, msd_hist_words(r0) * sizeof(u32));
         if (rc) return rc;
         rc = ensure_keep(c, c->a_rand, (c->a_rand.bytes >= r_have * 16 ? r_have : r_want) * 16, (size_t)r0 * 16);
         if (rc) return rc;
@@ -922,7 +922,7 @@ int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
         if (rc) return rc;
         rc = launch_extract(c, d_bases, d_offsets, n_reads, n_bases, cb, ce, range_begin, (u32)n_ranges,
                             c->KW == 2 ? (u64*)c->s_hi[0].p + c->acc_n : nullptr, (u64*)c->s_lo[0].p + c->acc_n,
-                            (u32*)c->a_hist.p + (size_t)r0 * KMC_MSD_NB, (u64*)c->a_rand.p + 2 * r0, (u64*)c->a_ror.p + 2 * r0);
+                            (u32*)c->a_hist.p, (u32)r0, (u64*)c->a_rand.p + 2 * r0, (u64*)c->a_ror.p + 2 * r0);
         if (rc) return rc;
         rc = launch_end(c);
         if (rc) return rc;
@@ -2372,6 +2372,13 @@ static int kmc_read_peak_device_impl(const void* d_buf, uint64_t n_bytes, int de
     return KMC_OK;
 }
 
+#ifdef KMC_LEAF_STAMPS
+extern "C" int kmc_debug_leaf_stamps(uint64_t* out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(kmc_leaf_stamps), 16 * sizeof(uint64_t)) != hipSuccess) return KMC_ERR_HIP;
+    if (reset) { uint64_t z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(kmc_leaf_stamps), z, sizeof(z)) != hipSuccess) return KMC_ERR_HIP; }
+    return KMC_OK;
+}
+#endif
 // ---- the ABI proper: no C++ exception leaves the library (kmc.h: "no exception or abort crosses the ABI") ----
 namespace {
 template <typename F>

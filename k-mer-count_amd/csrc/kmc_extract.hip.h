@@ -4,7 +4,7 @@
 // The reference materialises every window (k-mer-count/src/main.rs:63-81: push of a 54-byte String) and then groups
 // by sorting (main.rs:9-40,84,87).  Here the window loop writes 8-byte (16-byte for k >= 32) keys, and while a key is
 // still in a register the kernel also counts it into the level-0 digit histogram of its 65536-key range
-// (kmc_msd.hip.h: hist[r][1025]) and folds it into the range's AND / OR words -- what kmc_msd_hist_kernel would
+// (kmc_msd.hip.h: 1025 counters per range) and folds it into the range's AND / OR words -- what kmc_msd_hist_kernel would
 // otherwise compute by reading every key back from HBM (round 2: 1.46 ms per GB of all-distinct reads for that
 // re-read alone).  AND / OR stand in for the range's smallest / largest key: the sort only asks them "are all keys
 // equal" and "which is the highest bit in which two keys differ", and min ^ max and AND ^ OR answer both alike.
@@ -58,14 +58,15 @@ __device__ __forceinline__ void extract_store_half(u64* tr, int lane, const u64 
 }
 
 // Chunks [chunk_begin + 64 r, chunk_begin + 64 r + 64) are range r of this launch, r < n_ranges; its keys go to
-// out_lo / out_hi [65536 r, 65536 r + 65536), its histogram to hist[r][], its AND / OR words to rand[2 r ..] / ror[2 r ..]
+// out_lo / out_hi [65536 r, 65536 r + 65536), its histogram to range hist_r0 + r of hist (msd_hist_idx), its AND / OR words to
+// rand[2 r ..] / ror[2 r ..]
 // ({high, low} word, as kmc_msd_hist_kernel writes rmin / rmax).  Chunks at or past chunk_end (the padding of the last
 // range) and positions at or past n_bases hold filler; windows ending before range_begin belong to an earlier launch.
 template <int KW, bool CANON>
 __global__ __launch_bounds__(KMC_STREAM_THREADS)
 void kmc_extract_hist_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ offsets, u64 n_reads, int k,
                              u64 chunk_begin, u64 chunk_end, u64 range_begin, u32 n_ranges, u64* __restrict__ counters,
-                             u64* __restrict__ out_hi, u64* __restrict__ out_lo, u32* __restrict__ hist,
+                             u64* __restrict__ out_hi, u64* __restrict__ out_lo, u32* __restrict__ hist, u32 hist_r0,
                              u64* __restrict__ rand_, u64* __restrict__ ror_) {
     constexpr int NW = 2 * KW + 1;  // window words: own + 2*KW preceding lanes
     extern __shared__ __align__(16) unsigned char extract_smem[];
@@ -247,7 +248,7 @@ void kmc_extract_hist_kernel(const uint8_t* __restrict__ bases, u64 n_bases, con
         }
         if (lane == 0) { L.s_and[wv][0] = a_hi; L.s_and[wv][1] = a_lo; L.s_or[wv][0] = o_hi; L.s_or[wv][1] = o_lo; }
         __syncthreads();
-        for (u32 d = tid; d < KMC_MSD_NB; d += KMC_STREAM_THREADS) hist[(size_t)r * KMC_MSD_NB + d] = L.hist[d];
+        for (u32 d = tid; d < KMC_MSD_NB; d += KMC_STREAM_THREADS) hist[msd_hist_idx((size_t)hist_r0 + r, d)] = L.hist[d];
         if (tid == 0) {
             u64 ah = ~0ull, al = ~0ull, oh = 0, ol = 0;
             for (int w = 0; w < KMC_STREAM_WAVES; ++w) { ah &= L.s_and[w][0]; al &= L.s_and[w][1]; oh |= L.s_or[w][0]; ol |= L.s_or[w][1]; }

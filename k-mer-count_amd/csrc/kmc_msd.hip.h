@@ -78,6 +78,15 @@ struct MsdCtl {
                      // take 400 k same-address atomics on heavily repeated keys): pairs = valid keys - their sum
 };
 
+// Where the histograms live: counter (range r, digit d).  Blocks of 64 ranges, inside a block digit-major: the 64
+// ranges' counters of one digit are 256 contiguous bytes, so the column scans of kmc_msd_scan_a_kernel (a wave walks
+// ONE digit over its segment's ranges, 64 at a time) read and write whole lines.  Row-major hist[r][1025] made every
+// lane of those scans touch its own line: 0.8 ms per GB of keys at level 0 for 57 MB of counters.  The price is paid
+// by the writers (a range stores its 1025 counters 256 bytes apart) where it is hidden: fire-and-forget stores
+// behind kernels that move gigabytes.  A buffer for R ranges holds msd_hist_words(R) counters.
+__host__ __device__ __forceinline__ size_t msd_hist_idx(size_t r, u32 d) { return ((r >> 6) * KMC_MSD_NB + d) * 64 + (r & 63); }
+static inline size_t msd_hist_words(size_t n_ranges) { return ((n_ranges + 63) / 64) * 64 * (size_t)KMC_MSD_NB; }
+
 template <int KW>
 __device__ __forceinline__ bool msd_is_filler(u64 hi, u64 lo, int kb) {
     if (KW == 1) return kb < 64 && (lo >> kb) != 0;
@@ -186,7 +195,7 @@ __device__ __forceinline__ u32 msd_seg_of(const u32* __restrict__ first, u32 n_s
     return lo;
 }
 
-// per range: digit histogram (hist[r][NB]) and min / max key (all-equal segments end here)
+// per range: digit histogram (msd_hist_idx) and min / max key (all-equal segments end here)
 template <int KW>
 __global__ __launch_bounds__(KMC_MSD_THREADS)
 void kmc_msd_hist_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo0, const u64* __restrict__ hi1, const u64* __restrict__ lo1,
@@ -228,7 +237,7 @@ void kmc_msd_hist_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     }
     if ((tid & 63) == 0) { smin[wv][0] = mnh; smin[wv][1] = mnl; smax[wv][0] = mxh; smax[wv][1] = mxl; }
     __syncthreads();
-    for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_THREADS) hist[(size_t)r * KMC_MSD_NB + d] = h[0][d] + h[1][d] + h[2][d] + h[3][d];
+    for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_THREADS) hist[msd_hist_idx(r, d)] = h[0][d] + h[1][d] + h[2][d] + h[3][d];
     if (tid == 0) {
         for (int w = 1; w < 4; ++w) {
             if (key_less(smin[w][0], smin[w][1], mnh, mnl)) { mnh = smin[w][0]; mnl = smin[w][1]; }
@@ -254,7 +263,7 @@ void kmc_msd_scan_a_kernel(u32 n_seg, u32 S, const u32* __restrict__ first, u32*
         u32 run = 0;
         for (u32 base = r0; base < r1; base += 64) {
             const u32 r = base + lane;
-            const size_t i = (size_t)r * KMC_MSD_NB + d;
+            const size_t i = msd_hist_idx(r, d);
             const u32 v = r < r1 ? hist[i] : 0u;
             u32 inc = v;
 #pragma unroll
@@ -301,7 +310,7 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
         if (lane == 0) { smm[wv][0] = mnh; smm[wv][1] = mnl; smm[wv][2] = mxh; smm[wv][3] = mxl; }
     }
     if (r1 - r0 == 1) {  // a segment of one range (most segments below level 0): no column scan was run for it
-        for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_ND) { tot[d] = hist[(size_t)r0 * KMC_MSD_NB + d]; hist[(size_t)r0 * KMC_MSD_NB + d] = 0; }
+        for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_ND) { tot[d] = hist[msd_hist_idx(r0, d)]; hist[msd_hist_idx(r0, d)] = 0; }
     } else {
         for (u32 d = tid; d < KMC_MSD_NB; d += KMC_MSD_ND) tot[d] = stot[(size_t)s * KMC_MSD_NB + d];
     }
@@ -457,7 +466,7 @@ void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* _
     u64* const ohi = sp ? hi0 : hi1;
     u64* const olo = sp ? lo0 : lo1;
     u64* const ow = sp ? w0 : w1;
-    for (u32 d = tid; d < KMC_MSD_NB; d += 1024) L.cur[d] = cbase[(size_t)s * KMC_MSD_NB + d] + hist[(size_t)r * KMC_MSD_NB + d];
+    for (u32 d = tid; d < KMC_MSD_NB; d += 1024) L.cur[d] = cbase[(size_t)s * KMC_MSD_NB + d] + hist[msd_hist_idx(r, d)];
     const u32 idx = r - first[s];
     const u32 b = seg[s].begin + idx * KMC_MSD_RANGE;
     const u32 n = min((u32)KMC_MSD_RANGE, seg[s].len - idx * KMC_MSD_RANGE);
@@ -564,6 +573,13 @@ __global__ void kmc_msd_order_kernel(const MsdTerm* __restrict__ term, u32 n_ter
 // final dense place at once.  Exact, but 11.7 instead of 7.9 ms per GB: a leaf finishes together with the ~1,800 leaves
 // in flight around it, so the nearest inclusive prefix is a thousand terminals back and every workgroup ends up
 // waiting for the slowest of its neighbours -- profiles/r03_sort_leaf_variants.txt.)
+#ifdef KMC_LEAF_STAMPS
+// diagnostic build only (tools/leaf_stamps.py): cycles per phase of the leaf kernel, summed over all workgroups (thread 0's clock)
+__device__ unsigned long long kmc_leaf_stamps[16];
+#define LEAF_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&kmc_leaf_stamps[i], now_ - t_prev_); t_prev_ = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define LEAF_STAMP(i) do { } while (0)
+#endif
 template <int KW, bool WEIGHTS, int CAPV, int SCRV> struct MsdLeafLds {
     static constexpr int CAP = CAPV;   // leaf capacity (KMC_MSD_LEAF1 / LEAF2 / LEAF2W; two-word sorts also run with 1024)
     // ONE image of the leaf (the keys come in through registers: with a second image a one-word leaf took
@@ -613,6 +629,9 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     u64* const t_hi = T.parity ? s_hi0 : s_hi1;
     u64* const t_w = T.parity ? s_w0 : s_w1;
     const u32 n = T.len;
+#ifdef KMC_LEAF_STAMPS
+    unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
     // a terminal's n_mine pairs go to its own positions of the run; what it holds fewer pairs than keys is recorded
     auto account = [&](u32 n_mine) {   // (one lane)
         nd[t] = n_mine;
@@ -649,21 +668,56 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     constexpr int PER = MsdLeafLds<KW, WEIGHTS, CAPV, SCRV>::CAP / KMC_MSD_THREADS;  // keys per thread, in registers
     u64 rlo[PER], rhi[KW == 2 ? PER : 1], rw[WEIGHTS ? PER : 1];
     u64 mnh = ~0ull, mnl = ~0ull, mxh = 0, mxl = 0;
+    // The keys come in as ALIGNED PAIRS, 16 bytes per lane and load instruction (a wave-load = 1 KiB contiguous; 8-byte
+    // loads left this kernel at 2.5 TB/s).  Register slot s of the workgroup (thread t: slots 2 (t + 256 e) + {0, 1})
+    // holds key s + off of the terminal, off = T.begin & 1: with an odd begin the pairs start at the terminal's SECOND
+    // key and its first key goes to slot n - 1, which is free then.  Which key sits in which slot does not matter --
+    // the LDS pass below orders them.  (Half a pair may lie outside the terminal -- a neighbour's key, or up to 8
+    // bytes past the last key of the array, inside the allocation's slack: loaded, never used.)
+    static_assert(PER % 2 == 0, "keys per thread must be even");
+    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    const u32 off = T.begin & 1u;
+    bool rv[PER];   // slot holds a key
 #pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        const u32 i = tid + KMC_MSD_THREADS * e;
-        rlo[e] = 0;
-        if (KW == 2) rhi[e] = 0;
-        if (WEIGHTS) rw[e] = 0;
-        if (i < n) {
-            const u64 lo = klo[T.begin + i], hi = KW == 2 ? khi[T.begin + i] : 0ull;
-            rlo[e] = lo;
-            if (KW == 2) rhi[e] = hi;
-            if (WEIGHTS) rw[e] = kw[T.begin + i];
-            if (key_less(hi, lo, mnh, mnl)) { mnh = hi; mnl = lo; }
-            if (key_less(mxh, mxl, hi, lo)) { mxh = hi; mxl = lo; }
+    for (int e = 0; e < PER / 2; ++e) {
+        const u32 s0 = 2u * (tid + KMC_MSD_THREADS * e);   // first slot of the pair; its key is T.begin + off + s0 (an even index)
+        rlo[2 * e] = rlo[2 * e + 1] = 0;
+        if (KW == 2) rhi[2 * e] = rhi[2 * e + 1] = 0;
+        if (WEIGHTS) rw[2 * e] = rw[2 * e + 1] = 0;
+        rv[2 * e] = s0 + off < n;
+        rv[2 * e + 1] = s0 + 1 + off < n;
+        if (rv[2 * e]) {   // (the pair's first key is the terminal's: the pair is loaded)
+            const size_t g = (size_t)T.begin + off + s0;
+            const u64x2_t pl = *reinterpret_cast<const u64x2_t*>(klo + g);
+            rlo[2 * e] = pl.x; rlo[2 * e + 1] = pl.y;
+            if (KW == 2) { const u64x2_t ph = *reinterpret_cast<const u64x2_t*>(khi + g); rhi[2 * e] = ph.x; rhi[2 * e + 1] = ph.y; }
+            if (WEIGHTS) { const u64x2_t pw = *reinterpret_cast<const u64x2_t*>(kw + g); rw[2 * e] = pw.x; rw[2 * e + 1] = pw.y; }
+        }
+        if (off) {   // odd begin: the terminal's first key into slot n - 1
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (s0 + h == n - 1) {
+                    rlo[2 * e + h] = klo[T.begin];
+                    if (KW == 2) rhi[2 * e + h] = khi[T.begin];
+                    if (WEIGHTS) rw[2 * e + h] = kw[T.begin];
+                    rv[2 * e + h] = true;
+                }
+            }
         }
     }
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        if (rv[e]) {
+            const u64 lo = rlo[e], hi = KW == 2 ? rhi[e] : 0ull;
+            if (key_less(hi, lo, mnh, mnl)) { mnh = hi; mnl = lo; }
+            if (key_less(mxh, mxl, hi, lo)) { mxh = hi; mxl = lo; }
+        } else {
+            rlo[e] = 0;
+            if (KW == 2) rhi[e] = 0;
+            if (WEIGHTS) rw[e] = 0;
+        }
+    }
+    LEAF_STAMP(0);   // keys loaded (HBM latency)
     for (u32 i = tid; i < KMC_MSD_LEAF_NSB; i += KMC_MSD_THREADS) L.cnt[i] = 0;
     if (tid == 0) { L.bad = 0; L.n_out = 0; L.nbig = 0; }
 #pragma unroll
@@ -690,7 +744,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             __syncthreads();
             sw = 0;
 #pragma unroll
-            for (int e = 0; e < PER; ++e) if (tid + KMC_MSD_THREADS * e < n) sw += rw[e];
+            for (int e = 0; e < PER; ++e) if (rv[e]) sw += rw[e];
             sw = wave_sum_u64(sw);
             if (lane == 0) L.sx[wv][0] = sw;
             __syncthreads();
@@ -709,12 +763,13 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         if (shift == 0) return (u32)dl;
         return (u32)((dl >> shift) | (dh << (64 - shift)));
     };
+    LEAF_STAMP(1);   // min / max
     // 2. LDS pass: a -> b grouped by digit
     u32 rb[PER];  // sub-bucket of my keys
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
         rb[e] = bucket(KW == 2 ? rhi[e] : 0ull, rlo[e]) & (KMC_MSD_LEAF_NSB - 1u);
-        if (tid + KMC_MSD_THREADS * e < n) atomicAdd(&L.cnt[rb[e]], 1u);
+        if (rv[e]) atomicAdd(&L.cnt[rb[e]], 1u);
     }
     __syncthreads();
     {   // exclusive prefix of the sub-bucket sizes: four consecutive sub-buckets per thread
@@ -739,11 +794,12 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         if (tid == KMC_MSD_THREADS - 1) L.off[KMC_MSD_LEAF_NSB] = run;
         __syncthreads();
     }
+    LEAF_STAMP(2);   // count atomics + prefix
     u32 rp[PER];  // where my keys landed in b
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
         rp[e] = 0;
-        if (tid + KMC_MSD_THREADS * e < n) {
+        if (rv[e]) {
             const u32 p = atomicAdd(&L.cnt[rb[e]], 1u);
             rp[e] = p;
             L.b_lo[p] = rlo[e];
@@ -752,6 +808,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         }
     }
     __syncthreads();
+    LEAF_STAMP(3);   // cursor atomics + LDS scatter
     // 3a. small sub-buckets (three or four keys on average, at most THREAD_SORT): every KEY counts the keys of its
     //     sub-bucket that sort before it -- smaller, or equal and ahead of it in b -- and that count is its place.
     //     The keys are still in their owners' registers, so the sorted image is written over b in place.  (Round 2
@@ -786,7 +843,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
 #else
 #pragma unroll
     for (int e = 0; e < PER; ++e) {
-        if (tid + KMC_MSD_THREADS * e < n) {
+        if (rv[e]) {
             const u32 o = L.off[rb[e]], m = L.off[rb[e] + 1] - o;
             if (m > 1 && m <= KMC_MSD_THREAD_SORT) {
                 const u64 mlo = rlo[e], mhi = KW == 2 ? rhi[e] : 0ull;
@@ -814,6 +871,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         }
     }
     __syncthreads();
+    LEAF_STAMP(4);   // rank count + rewrite
     // 3b. larger sub-buckets, one wave each.  Keys of real inputs cluster (families of k-mers that share
     //     all but their last few bases sit in ONE sub-bucket while the leaf's range is set by the distance
     //     between families), so a large sub-bucket is first split again by ITS OWN key range into 128
@@ -1008,57 +1066,86 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             }
         }
     }
+    LEAF_STAMP(5);   // large sub-buckets
     // 4. run-length over the sorted image b[0..n).  Phase 1: the position of every run head, compacted
     //    (16 bits each, in the space of the sub-bucket counters and offsets, dead by now); phase 2: one thread per run -- its length is the distance
     //    to the next head (the first version let the head's thread walk its run: one thread, thousands of
     //    dependent LDS reads for a key with thousands of copies, everybody else waiting at the barrier).
     static_assert(sizeof(L.cnt) + sizeof(L.off) >= MsdLeafLds<KW, WEIGHTS, CAPV, SCRV>::CAP * sizeof(unsigned short), "run-head list does not fit");
     unsigned short* const hidx = reinterpret_cast<unsigned short*>(L.cnt);
-    for (u32 c0 = 0; c0 < n; c0 += KMC_MSD_THREADS * 4) {
-        const u32 i0 = c0 + tid * 4;  // each thread owns 4 consecutive elements of this slab
-        u32 nh = 0;
-        bool head[4];
+    // Element i = tid + 256 e of the sorted image is a run head when it differs from element i - 1 (strided: conflict-free
+    // LDS reads).  Heads are numbered in element order -- slab e before slab e + 1, inside a slab by thread -- with ONE
+    // ballot per slab and wave and one small table of (slab, wave) totals: two barriers for the whole leaf (the first
+    // version scanned slabs of 1024 elements one after the other, four barriers each).
+    constexpr int NSLAB = MsdLeafLds<KW, WEIGHTS, CAPV, SCRV>::CAP / KMC_MSD_THREADS;
+    u32 hmask = 0;          // bit e: my element of slab e is a run head
+    u32 hpre[NSLAB];        // heads of lower lanes of my wave in slab e
+    u32* const stot = L.big;   // [NSLAB][4] heads per (slab, wave) (the list of large sub-buckets is dead by now)
+    static_assert(sizeof(L.big) >= NSLAB * 4 * sizeof(u32), "head totals do not fit");
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const u32 i = i0 + e;
-            bool h = false;
-            if (i < n) h = i == 0 || L.b_lo[i] != L.b_lo[i - 1] || (KW == 2 && L.b_hi[i] != L.b_hi[i - 1]);
-            head[e] = h;
-            nh += h ? 1u : 0u;
-        }
-        u32 inc = nh;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
-        __syncthreads();
-        if (lane == 63) L.wsum[wv] = inc;
-        __syncthreads();
-        u32 wbase = L.n_out;
-        for (u32 w = 0; w < wv; ++w) wbase += L.wsum[w];
-        u32 pos = wbase + inc - nh;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (i0 + e < n && head[e]) hidx[pos++] = (unsigned short)(i0 + e);
-        __syncthreads();
-        if (tid == KMC_MSD_THREADS - 1) L.n_out = pos;  // (the last thread's end = the slab's end)
-        __syncthreads();
+    for (int e = 0; e < NSLAB; ++e) {
+        const u32 i = tid + KMC_MSD_THREADS * e;
+        bool h = false;
+        if (i < n) h = i == 0 || L.b_lo[i] != L.b_lo[i - 1] || (KW == 2 && L.b_hi[i] != L.b_hi[i - 1]);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(h);
+        hmask |= h ? (1u << e) : 0u;
+        hpre[e] = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+        if (lane == 0) stot[e * 4 + wv] = (u32)__popcll(m);
     }
-    const u32 n_out = L.n_out;
-    // 5. out: straight into the run, at the terminal's own positions
+    __syncthreads();   // (every element has been compared: the counters under hidx may be overwritten)
+    u32 run = 0, n_heads = 0;
+    {
+        u32 my_base[NSLAB];
+#pragma unroll
+        for (int e = 0; e < NSLAB; ++e) {
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { if (w == (int)wv) my_base[e] = run; run += stot[e * 4 + w]; }
+        }
+        n_heads = run;
+#pragma unroll
+        for (int e = 0; e < NSLAB; ++e) if (hmask & (1u << e)) hidx[my_base[e] + hpre[e]] = (unsigned short)(tid + KMC_MSD_THREADS * e);
+    }
+    __syncthreads();
+    LEAF_STAMP(6);   // run heads
+    const u32 n_out = n_heads;
+    // 5. out: straight into the run, at the terminal's own positions, two pairs per lane and store where they are aligned
+    //    (run index T.begin + r even): 16-byte stores, 1 KiB per wave instruction
     if (tid == 0) account(n_out);
     const u32 base = T.begin;
     u64 wtot = 0;
-    for (u32 r = tid; r < n_out; r += KMC_MSD_THREADS) {
+    auto pair_of = [&](u32 r, u64& khi_o, u64& klo_o, u64& c_o) {
         const u32 i = hidx[r], iend = r + 1 < n_out ? hidx[r + 1] : n;
         u64 sum = iend - i;
         if (WEIGHTS) { sum = 0; for (u32 j = i; j < iend; ++j) sum += L.b_w[j]; }
-        o_lo[base + r] = L.b_lo[i];
-        if (KW == 2) o_hi[base + r] = L.b_hi[i];
-        o_cnt[base + r] = sum;
+        klo_o = L.b_lo[i];
+        khi_o = KW == 2 ? L.b_hi[i] : 0ull;
+        c_o = sum;
         wtot += sum;
+    };
+    const u32 lead = (base & 1u) && n_out ? 1u : 0u;   // an odd first position: that pair alone
+    if (tid == 0 && lead) {
+        u64 a, b, cn;
+        pair_of(0, a, b, cn);
+        o_lo[base] = b; if (KW == 2) o_hi[base] = a; o_cnt[base] = cn;
+    }
+    for (u32 r = lead + 2u * tid; r < n_out; r += 2u * KMC_MSD_THREADS) {
+        u64 h0, l0, c0, h1 = 0, l1 = 0, c1 = 0;
+        pair_of(r, h0, l0, c0);
+        if (r + 1 < n_out) {
+            pair_of(r + 1, h1, l1, c1);
+            const size_t g = (size_t)base + r;   // even
+            *reinterpret_cast<u64x2_t*>(o_lo + g) = u64x2_t{l0, l1};
+            if (KW == 2) *reinterpret_cast<u64x2_t*>(o_hi + g) = u64x2_t{h0, h1};
+            *reinterpret_cast<u64x2_t*>(o_cnt + g) = u64x2_t{c0, c1};
+        } else {
+            o_lo[base + r] = l0; if (KW == 2) o_hi[base + r] = h0; o_cnt[base + r] = c0;
+        }
     }
     if (WEIGHTS) {
         wtot = wave_sum_u64(wtot);
         if (lane == 0 && wtot) atomicAdd(&ctl->w_total, (unsigned long long)wtot);
     }
+    LEAF_STAMP(7);   // pairs out (issue)
 }
 
 // dense run: terminal t's nd[t] pairs move from its own positions of the sparse run (s_*) to base[t] of the dense one

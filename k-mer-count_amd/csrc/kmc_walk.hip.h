@@ -495,7 +495,10 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     // 12 % slower still -- vector memory returns in issue order, so a returning device-scope atomic
     // (microseconds under load) holds back every load the wave issued after it, however late its
     // result is read; per-XCD tile shares learned from the previous launch's loop times changed
-    // nothing (1.319 vs 1.320 ms), the past launch does not predict the next.)
+    // nothing (1.319 vs 1.320 ms), the past launch does not predict the next.  Round 3: ONE work queue for the whole launch,
+    // tiles dealt in chunks of 16, the ticket drawn two chunks ahead by the wave that takes a chunk's first tile and issued
+    // right in front of its step phase, so that nothing ever waits for it -- exact, and 3 % SLOWER at 10 GB (1.393 vs
+    // 1.352 ms) and 2 % slower at 1 GB: whatever spreads the XCDs' finish times, it is not a shortage of tiles.)
     auto tile_of = [&](u32 j) { return tile_begin + blockIdx.x + (u64)gridDim.x * j; };
     const u64 gw = tile_of((u32)wv);  // the first tile of every wave is fixed; the counter starts behind them
 
