@@ -773,7 +773,9 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
         else hipLaunchKernelGGL(kmc_msd_hist_kernel<2>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1],
                                 (const MsdSeg*)seg, n_seg, (const u32*)first, (int)kb, l == 0 ? 1 : 0, hist_l, rmin_l, rmax_l, (const MsdCtl*)ctl);
         HIPCHK(c, hipMemsetAsync(&ctl->n_next, 0, sizeof(u32), c->stream));
-        const u32 S = n_seg <= 4096 ? 64u : 1u;  // few segments = long ones: digit columns spread over 64 workgroups
+        // few segments = long ones: a wave per digit column (257 workgroups of four waves for a single segment: level 0),
+        // 64 workgroups per segment while there are few, one when there are many (short ones)
+        const u32 S = n_seg <= 8 ? 257u : (n_seg <= 4096 ? 64u : 1u);
         hipLaunchKernelGGL(kmc_msd_scan_a_kernel, dim3(n_seg * S), dim3(KMC_MSD_THREADS), 0, c->stream, n_seg, S, (const u32*)first, hist_l, (u32*)c->m_stot.p);
         hipLaunchKernelGGL(kmc_msd_scan_kernel, dim3(n_seg), dim3(KMC_MSD_ND), 0, c->stream, (const MsdSeg*)seg, n_seg, (const u32*)first, hist_l, (const u32*)c->m_stot.p,
                            (const u64*)rmin_l, (const u64*)rmax_l, (u32*)c->m_cbase.p, (u32*)c->m_skip.p, l == 0 ? 1 : 0, leaf_cap,
