@@ -28,6 +28,7 @@
 #include "kmc_synth.hip.h"
 #include "kmc_table.hip.h"
 #include "kmc_walk.hip.h"
+#include "kmc_sklog.hip.h"
 #include "kmc_lr.hip.h"
 #include "kmc_msd.hip.h"
 #include "kmc_extract.hip.h"
@@ -90,6 +91,10 @@ struct kmc_ctx {
     bool walk_ws_clean = false;  // workspace header + dense counters are zero (left so by kmc_walk_tail_kernel)
     // KMC_ALGO_SORT: scratch for one sub-batch and the sorted (key,count) runs produced so far
     DevBuf s_lo[2], s_hi[2];
+    // the walk kernel's log of steps that fell off its LDS memo (kmc_walk.hip.h SkLog, kmc_sklog.hip.h): per-workgroup spans,
+    // their fill counts, the 1024 hash bins the records are partitioned into, the bins' cursors
+    DevBuf lg_rec, lg_count, lg_bins, lg_cursor;
+    bool sklog_on = false;   // this data source overflows the LDS memo (a poll saw (k+16)-mers in the second-level table): log from now on
     DevBuf a_hist, a_rand, a_ror;   // level-0 histogram rows / AND / OR words of the accumulated key ranges (kmc_extract.hip.h)
     // KMC_ALGO_SORT accumulates: a batch only EXTRACTS its keys behind those of the batches before it (s_lo[0] /
     // s_hi[0]); they are sorted into ONE run when somebody needs the result (kmc_finalize, a reduce) or when 2^31
@@ -117,6 +122,7 @@ struct kmc_ctx {
     // KMC_ALGO_AUTO chooses by MEASURED cost: kernel milliseconds per base of this ctx's recent walk-path batches (walk
     // kernel + (k+16)-mer unfold + the table merge at finalize) and sort-path batches (< 0: not measured yet)
     double walk_ms_per_base = -1.0, sort_ms_per_base = -1.0;
+    bool sort_by_cost = false;   // AUTO: the last comparison of the two rates said "sort" (prefer_sort: structural -- the source overflowed everything)
     std::vector<hipEvent_t> ev_free;          // events to reuse
     kmc_stats st{};
     int fin_parity = 0;    // which OUT/SUM counter pair the next kmc_finalize uses
@@ -435,6 +441,7 @@ int poll_book(kmc_ctx* c) {
         u64 d = c->h_counters[KMC_CTR_BADBASE], n = c->h_counters[KMC_CTR_KMERS];
         u64 dd = d - c->direct_seen, dn = n - c->kmers_seen;
         if (d >= c->direct_seen && n > c->kmers_seen && (c->st.algo_last == KMC_ALGO_WALK || c->st.algo_last == KMC_ALGO_STREAM)) c->walk_overflowed = dd * 20 > dn;
+        if (c->sk.lo && c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] != 0) c->sklog_on = true;   // (the memo overflows on this source)
         // the second-level memo more than half full: this input has too many distinct (k+16)-mers for it
         if (c->sk.lo && (c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL]) * 2 > c->sk.cap) {
             if (!c->sk_fixed && c->sk.cap < (1ull << 24)) c->sk_grow = true;  // (first: a larger one)
@@ -1087,6 +1094,31 @@ int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
 }
 
 void harvest_timing(kmc_ctx* c);
+// the two kernels behind a walk launch that logged (kmc_sklog.hip.h)
+int launch_sklog(kmc_ctx* c, const SkLog& lg, u32 wgrid, u32 slices, u32 bin_cap) {
+    GTable g = gtable_of(c, c->tab);
+    const bool canon = c->cfg.canonical != 0;
+    const int k = c->cfg.k;
+    u64* bins = (u64*)c->lg_bins.p;
+    u32* cur = (u32*)c->lg_cursor.p;
+#define SKLOG_LAUNCH(KWV, CAN, WV)                                                                                                           \
+    do {                                                                                                                                     \
+        static std::atomic<unsigned long long> attr{0};                                                                                      \
+        if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_sklog_consume_kernel<KWV, CAN, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SklogTable<WV>)); \
+        hipLaunchKernelGGL((kmc_sklog_partition_kernel<KWV, CAN, WV>), dim3(wgrid * slices), dim3(1024), 0, c->stream, (const u64*)lg.rec, (const u32*)lg.count, lg.cap_wg, slices, bins, cur, bin_cap, k, g); \
+        hipLaunchKernelGGL((kmc_sklog_consume_kernel<KWV, CAN, WV>), dim3(KMC_SKLOG_BINS), dim3(1024), sizeof(SklogTable<WV>), c->stream, (const u64*)bins, (const u32*)cur, bin_cap, k, g); \
+    } while (0)
+    if (lg.words == 2) {
+        if (c->KW == 1) { if (canon) SKLOG_LAUNCH(1, true, 2); else SKLOG_LAUNCH(1, false, 2); }
+        else { if (canon) SKLOG_LAUNCH(2, true, 2); else SKLOG_LAUNCH(2, false, 2); }
+    } else {
+        if (canon) SKLOG_LAUNCH(2, true, 4); else SKLOG_LAUNCH(2, false, 4);
+    }
+#undef SKLOG_LAUNCH
+    HIPCHK(c, hipGetLastError());
+    return KMC_OK;
+}
+
 // kernel milliseconds per base of the sort path on all-distinct reads (1 GB FASTA = 0.914 G bases; profiles/r03_sort_*):
 // the prior of KMC_ALGO_AUTO's cost comparison until the ctx has sorted something itself
 #define KMC_SORT_MS_PER_BASE_1 2.9e-8
@@ -1122,12 +1154,14 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     int algo = c->cfg.algo;
     if (c->cfg.mode == KMC_MODE_LR) algo = KMC_ALGO_STREAM;  // LR runs its own kernel (kmc_lr.hip.h)
     if (algo == KMC_ALGO_AUTO && !c->prefer_sort && c->walk_ms_per_base > 0) {
-        // by measured cost: the walk path (memo overflow: (k+16)-mer table updates, unfold, table merge) against what sorting
-        // costs on this GPU -- this ctx's own measurement when it has one, else the rate of all-distinct reads
+        // by measured cost: the walk path (memo overflow: logged steps, (k+16)-mer table updates, unfold, table merge) against what
+        // sorting costs -- this ctx's own measurement on this source when it has one (heavily repeated keys sort at half the
+        // rate of distinct ones), else the rate of all-distinct reads on this GPU.  Both ways: a source that
+        // turned out to sort slower than it walks goes back to walking.
         const double sort_est = c->sort_ms_per_base > 0 ? c->sort_ms_per_base : (c->KW == 1 ? KMC_SORT_MS_PER_BASE_1 : KMC_SORT_MS_PER_BASE_2);
-        if (c->walk_ms_per_base > 1.1 * sort_est) c->prefer_sort = true;
+        c->sort_by_cost = c->walk_ms_per_base > 1.1 * sort_est;
     }
-    if (algo == KMC_ALGO_AUTO && c->prefer_sort) algo = KMC_ALGO_SORT;
+    if (algo == KMC_ALGO_AUTO && (c->prefer_sort || c->sort_by_cost)) algo = KMC_ALGO_SORT;
     if (algo == KMC_ALGO_AUTO || algo == KMC_ALGO_WALK) {
         if (!max_read_len) {
             HIPCHK(c, hipMemsetAsync(&c->d_counters[KMC_CTR_MAXLEN], 0, sizeof(u64), c->stream));
@@ -1333,6 +1367,30 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                         !arm_risky(c, d_bases, d_offsets, n_reads, n_bases, 0, done ? d_ve + (done * 64 - 1) : nullptr))
                         skt = GTable{};
                 }
+                // the log of the steps that fall off the LDS memo (kmc_sklog.hip.h), sized for the worst case -- every step of the
+                // launch -- up to 12 GiB; a workgroup whose span is full goes on with (k+16)-mer table updates
+                SkLog lg{};
+                u32 lg_slices = 0, lg_bin_cap = 0;
+                const int wgrid = kmc_walk_grid(take, c->n_cu);
+                if (c->sklog_on && skt.key_lo && !getenv("KMC_NO_SKLOG")) {
+                    const u32 words = c->cfg.k > KMC_SK_MAX_K ? 4u : 2u;
+                    const u64 steps_per_read = std::min<u64>(std::max<u64>(max_read_len, 1), KMC_WALK_MAX_READ) / KMC_WALK_STRIDE + 1;
+                    u64 cap = ((take + wgrid - 1) / wgrid + 1) * 64ull * steps_per_read;
+                    cap = std::min<u64>(cap, (12ull << 30) / ((u64)wgrid * words * sizeof(u64)));
+                    cap = std::max<u64>(cap, 1024);
+                    const u64 bin_cap = ((u64)wgrid * cap / KMC_SKLOG_BINS) * 5 / 4 + 1024;
+                    if (cap < (1ull << 31) && bin_cap < (1ull << 31) &&
+                        !ensure(c, c->lg_rec, (size_t)wgrid * cap * words * sizeof(u64)) && !ensure(c, c->lg_bins, (size_t)KMC_SKLOG_BINS * bin_cap * words * sizeof(u64)) &&
+                        !ensure(c, c->lg_count, (size_t)c->n_cu * sizeof(u32)) && !ensure(c, c->lg_cursor, KMC_SKLOG_BINS * sizeof(u32))) {
+                        HIPCHK(c, hipMemsetAsync(c->lg_count.p, 0, (size_t)c->n_cu * sizeof(u32), c->stream));
+                        HIPCHK(c, hipMemsetAsync(c->lg_cursor.p, 0, KMC_SKLOG_BINS * sizeof(u32), c->stream));
+                        lg = SkLog{(u64*)c->lg_rec.p, (u32*)c->lg_count.p, (u32)cap, words};
+                        lg_slices = (u32)((cap + KMC_SKLOG_SLICE - 1) / KMC_SKLOG_SLICE);
+                        lg_bin_cap = (u32)bin_cap;
+                    } else {
+                        c->err[0] = 0;   // (no memory for a log: the launch runs with table updates, as before)
+                    }
+                }
                 if (!c->walk_ws_clean) {  // (normally the unfold kernel of the previous launch left it clean)
                     rc = kmc_walk_prepare(c->stream, c->walk_ws.p);
                     if (rc) return fail(c, rc, "walk workspace reset failed");
@@ -1341,14 +1399,22 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 rc = launch_begin(c);  // the event pair brackets the walk kernel alone
                 if (rc) return rc;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
-                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), skt, 0);
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), skt, lg, 0);
                 if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
                 rc = launch_end(c);
                 if (rc) return rc;
                 if (skt.key_lo) c->sk_dirty = true;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
-                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), skt, 1);
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), skt, lg, 1);
                 if (rc) return fail(c, rc, "scalar/unfold kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+                if (lg.rec) {   // count what the launch logged: partition by hash, LDS tables, one unfold per distinct (k+16)-mer
+                    rc = launch_begin(c);
+                    if (rc) return rc;
+                    rc = launch_sklog(c, lg, (u32)wgrid, lg_slices, lg_bin_cap);
+                    if (rc) return rc;
+                    rc = launch_end(c);
+                    if (rc) return rc;
+                }
                 c->walk_ws_clean = true;
                 c->memo_parity ^= 1;
                 c->pending = true;
@@ -1503,6 +1569,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     DevBuf* bufs[] = {&c->st_bases, &c->st_offsets, &c->o_hi, &c->o_lo, &c->o_cnt, &c->t_hi, &c->t_lo, &c->t_cnt,
                       &c->t_idx0, &c->p_hi, &c->p_lo, &c->p_cnt, &c->walk_ws, &c->walk_memo, &c->vr_reads, &c->vr_cnt, &c->vr_pos,
                       &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->lr_rank, &c->a_hist, &c->a_rand, &c->a_ror,
+                      &c->lg_rec, &c->lg_count, &c->lg_bins, &c->lg_cursor,
                       &c->m_hist, &c->m_stot, &c->m_bsum, &c->m_rmin, &c->m_rmax, &c->m_seg[0], &c->m_seg[1], &c->m_first, &c->m_cbase, &c->m_skip, &c->m_term, &c->m_ord,
                       &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_w[0], &c->m_w[1],
                       &c->snap_hi, &c->snap_lo, &c->snap_cnt, &c->snap_n, &c->snap_occ, &c->rx_hi, &c->rx_lo, &c->rx_cnt};
@@ -2018,6 +2085,7 @@ static int kmc_forget_source_impl(kmc_ctx* c, int what) {
         HIPCHK(c, hipMemsetAsync(c->walk_memo.p, 0, kmc_walk_memo_bytes(c->n_cu, c->KW), c->stream));  // tag 0 = no snapshot
         c->memo_parity = 0;
     }
+    if (what & KMC_FORGET_MEMO) c->sklog_on = false;
     if (what & KMC_FORGET_MEMO) {
         // the (k+16)-mer table holds COUNTS as well as structure (walk launches add to it, the unfold into the
         // count table is deferred): give them to their k-mers first -- stream order puts the unfold ahead of
@@ -2035,6 +2103,7 @@ static int kmc_forget_source_impl(kmc_ctx* c, int what) {
         c->rho_last = c->rho_max = 0.0;
         c->prefer_sort = false;
         c->walk_ms_per_base = c->sort_ms_per_base = -1.0;
+        c->sort_by_cost = false;
         c->msd_dup_heavy = false;
         c->walk_overflowed = false;
     }

@@ -82,6 +82,7 @@ struct WalkLds {
     u32 badbits[KMC_WALK_WAVES][KMC_WALK_BADWORDS];
     u32 nedges, nnodes;
     u32 qnext;  // next unclaimed tile of this workgroup (waves draw their tiles from it)
+    u32 logn;   // records this workgroup has put into its span of the (k+16)-mer log (SkLog)
 };
 
 // workspace (device): [WalkWs header | gcnt[NCAP+ECAP] dense snapshot counters | u32 deferred read
@@ -264,11 +265,34 @@ __device__ __forceinline__ u32 walk_node(WalkLds<KW>& L, WCtx nk) {
 // the (k+16)-mer of a step: context (2k bits, public code, newest base lowest) followed by the label
 // (16 bases, internal code, first base in the low bits)
 // count one traversal of the step (ctx, label) in the (k+16)-mer table
-__device__ __forceinline__ void sk_add(const GTable& sk, WCtx ctx, u32 label) {
+// Round 3: the steps that fall off the LDS memo are LOGGED instead -- a fire-and-forget store of the (k+16)-mer into the
+// workgroup's own span of a log, position from a counter in LDS -- and counted after the launch by kmc_sklog.hip.h
+// (partition the log by a hash of the record, count each part in an LDS table, unfold every distinct (k+16)-mer once).
+// A hash-table update per step was what the plateau of pools 32..100 cost: 28 M scattered read-modify-writes per GB of
+// reads at ~7 G/s (round 2: 5.6-6.6 ms per GB; the walk itself 1.05 ms with the steps only logged).  A workgroup whose
+// span is full goes on with the table update (the table stays: first launch on a new source, overflow of the log).
+struct SkLog {
+    u64* rec;      // nullptr: no log; else spans of cap_wg records of `words` u64 each, workgroup b's span at b * cap_wg
+    u32* count;    // count[b] = records workgroup b wrote
+    u32 cap_wg;
+    u32 words;     // 2: {lo, mid} (k <= 47); 4: {lo, mid, top, 0} (k >= 48)
+};
+template <int KW>
+__device__ __forceinline__ void sk_add(WalkLds<KW>& L, const GTable& sk, const SkLog& lg, WCtx ctx, u32 label) {
     const u32 pub = label ^ ((label >> 1) & 0x55555555u);  // A0 C1 T2 G3 -> A0 C1 G2 T3
     const u32 be = le_to_be(pub);                           // first base of the step in the top bits
     const u64 lo = (ctx.lo << 32) | be;
     const u64 mid = (ctx.hi << 32) | (ctx.lo >> 32);
+    if (lg.rec) {
+        const u32 idx = atomicAdd(&L.logn, 1u);
+        if (idx < lg.cap_wg) {
+            typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+            u64x2_t* r = reinterpret_cast<u64x2_t*>(lg.rec + ((size_t)blockIdx.x * lg.cap_wg + idx) * lg.words);
+            r[0] = u64x2_t{lo, mid};
+            if (lg.words == 4) r[1] = u64x2_t{ctx.hi >> 32, 0ull};
+            return;
+        }
+    }
     if (sk.key_mid) gtable_add<3>(sk, ctx.hi >> 32, lo, 1, mid);
     else gtable_add<2>(sk, mid, lo, 1);
 }
@@ -324,11 +348,11 @@ __global__ void kmc_sk_spill_reset_kernel(GTable sk) {
 // Slow path of one step from node offset `s` (s == 0: direct mode).  Returns the next state.
 template <int KW, bool CANON>
 __device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s, u32 label, int len, int k,
-                                         u64 mask_hi, u64 mask_lo, WCtx& dctx, u32& ddepth, u64& ndirect, u32 cpar, const GTable& sk) {
+                                         u64 mask_hi, u64 mask_lo, WCtx& dctx, u32& ddepth, u64& ndirect, u32 cpar, const GTable& sk, const SkLog& lg) {
     if (s == 0) {  // direct mode: no node of the LDS memo stands for this lane's context
         if (sk.key_lo && len == KMC_WALK_STRIDE && ddepth >= (u32)k) {
             // a full step from a k-mer context: one add of its (k+16)-mer (second-level memo, above)
-            sk_add(sk, dctx, label);
+            sk_add<KW>(L, sk, lg, dctx, label);
             (void)walk_roll<KW, CANON, false>(g, dctx, ddepth, label, len, k, mask_hi, mask_lo, 0);
         } else {
             ndirect += walk_roll<KW, CANON, true>(g, dctx, ddepth, label, len, k, mask_hi, mask_lo, 1);
@@ -410,7 +434,7 @@ __device__ __forceinline__ u32 walk_slow(WalkLds<KW>& L, const GTable& g, u32 s,
     u32 depth;
     node_decode<KW>(node_key_load<KW>(L, id), k, ctx, depth);
     if (sk.key_lo && len == KMC_WALK_STRIDE && depth >= (u32)k) {
-        sk_add(sk, ctx, label);
+        sk_add<KW>(L, sk, lg, ctx, label);
         (void)walk_roll<KW, CANON, false>(g, ctx, depth, label, len, k, mask_hi, mask_lo, 0);
     } else {
         ndirect += walk_roll<KW, CANON, true>(g, ctx, depth, label, len, k, mask_hi, mask_lo, 1);
@@ -451,7 +475,7 @@ template <int KW, bool CANON>
 __global__ __launch_bounds__(KMC_WALK_THREADS)
 void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ vstart, const u64* __restrict__ vend, u64 n_reads,
                      int k, u64 tile_begin, u64 tile_end, WalkWs* ws, u32* deferred, const WalkMemoSlot<KW>* memo,
-                     WalkMemoSlot<KW>* memo_out, u64* gcnt, GTable g, GTable sk) {
+                     WalkMemoSlot<KW>* memo_out, u64* gcnt, GTable g, GTable sk, SkLog lg) {
     extern __shared__ __align__(16) unsigned char walk_smem[];
     WalkLds<KW>& L = *reinterpret_cast<WalkLds<KW>*>(walk_smem);
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -469,7 +493,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         L.node[i].cnt[0] = 0;
         L.node[i].cnt[1] = 0;
     }
-    if (tid == 0) { L.nedges = warm ? memo->nedges : 0; L.nnodes = warm ? memo->nnodes : 1; L.qnext = KMC_WALK_WAVES; }
+    if (tid == 0) { L.nedges = warm ? memo->nedges : 0; L.nnodes = warm ? memo->nnodes : 1; L.qnext = KMC_WALK_WAVES; L.logn = 0; }
     __syncthreads();
     const WCtx root_key = node_encode<KW>(WCtx{0, 0}, 0, k, mask_hi, mask_lo);  // prefix node of depth 0
     u32 root_id = (u32)(kmc_hash_key<KW>(root_key.hi, root_key.lo) >> (64 - KMC_WALK_NLOG));
@@ -657,7 +681,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
                     s = (u32)(pe >> 32);
                 } else {
                     if (!full) label &= (1u << (2 * tail)) - 1u;
-                    s = walk_slow<KW, CANON>(L, g, s, label, full ? KMC_WALK_STRIDE : (int)tail, k, mask_hi, mask_lo, dctx, ddepth, ndirect, cpar, sk);
+                    s = walk_slow<KW, CANON>(L, g, s, label, full ? KMC_WALK_STRIDE : (int)tail, k, mask_hi, mask_lo, dctx, ddepth, ndirect, cpar, sk, lg);
                 }
             }
         }
@@ -737,6 +761,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     // dependent ones on the few threads that happened to own a used entry (measured: 140 us -> the
     // flush used to be 8 % of the whole kernel).
     __syncthreads();
+    if (tid == 0 && lg.count) lg.count[blockIdx.x] = min(L.logn, lg.cap_wg);   // (every wave has finished its tiles)
     unsigned short* flist = reinterpret_cast<unsigned short*>(L.stage[0]);  // up to NCAP + ECAP entry indices
     u32* fcount = &L.badbits[0][0];
     if (tid == 0) *fcount = 0;
@@ -933,14 +958,14 @@ static inline size_t kmc_walk_workspace_bytes(u64 n_reads) { return KMC_WALK_WS_
 
 template <int KW, bool CANON>
 static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const uint8_t* d_bases, const u64* d_vstart, const u64* d_vend,
-                                     u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, u64* gcnt, void* memo, int parity, GTable g, GTable sk, int phase) {
+                                     u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, u64* gcnt, void* memo, int parity, GTable g, GTable sk, SkLog lg, int phase) {
     const size_t smem = sizeof(WalkLds<KW>);
     static std::atomic<unsigned long long> attr{0};  // one flag per instantiation and device
     if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<KW, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     WalkMemoSlot<KW>* slots = (WalkMemoSlot<KW>*)memo;
     if (phase == 0) {
         hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_vstart, d_vend, n_reads, k, tile_begin, tile_end, hdr, list,
-                           (const WalkMemoSlot<KW>*)&slots[parity], &slots[parity ^ 1], gcnt, g, sk);
+                           (const WalkMemoSlot<KW>*)&slots[parity], &slots[parity ^ 1], gcnt, g, sk, lg);
     } else {
         static_assert(((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE) % 256 == 0 && 256 % KMC_WALK_STRIDE == 0, "unfold grid must cover the items exactly");
         hipLaunchKernelGGL((kmc_walk_tail_kernel<KW, CANON>), dim3(KMC_WALK_UNFOLD_BLOCKS + n_cu), dim3(256), 0, st,
@@ -969,22 +994,26 @@ static inline int kmc_sk_unfold_launch(hipStream_t st, int n_cu, int KW, int k, 
 static inline int kmc_walk_prepare(hipStream_t st, void* ws) {
     return hipMemsetAsync(ws, 0, KMC_WALK_WS_PREFIX, st) == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
+// workgroups of a walk launch over n_tiles tiles (one 160 KB workgroup per CU is resident)
+static inline int kmc_walk_grid(u64 n_tiles, int n_cu) {
+    const u64 want = (n_tiles + KMC_WALK_WAVES - 1) / KMC_WALK_WAVES;
+    const int grid = (int)(want < (u64)n_cu ? want : (u64)n_cu);
+    return grid < 1 ? 1 : grid;
+}
 static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool canon, const uint8_t* d_bases,
-                                  const u64* d_vstart, const u64* d_vend, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, int parity, GTable g, GTable sk, int phase) {
+                                  const u64* d_vstart, const u64* d_vend, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, int parity, GTable g, GTable sk, SkLog lg, int phase) {
     if (n_reads >= (1ull << 32) || tile_end <= tile_begin) return KMC_ERR_ARG;
     WalkWs* hdr = (WalkWs*)ws;
     u32* list = (u32*)((char*)ws + KMC_WALK_WS_PREFIX);
     u64* gcnt_ws = (u64*)((char*)ws + sizeof(WalkWs));
     const u64 n_tiles = tile_end - tile_begin;
-    u64 want = (n_tiles + KMC_WALK_WAVES - 1) / KMC_WALK_WAVES;
-    int grid = (int)(want < (u64)n_cu ? want : (u64)n_cu);  // one 160 KB workgroup per CU is resident
-    if (grid < 1) grid = 1;
+    const int grid = kmc_walk_grid(n_tiles, n_cu);
     if (KW == 1) {
-        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, phase);
-        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, phase);
+        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase);
+        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase);
     } else {
-        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, phase);
-        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, phase);
+        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase);
+        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase);
     }
     return hipGetLastError() == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
