@@ -117,7 +117,7 @@ struct kmc_ctx {
     // hipEvent pairs bracketing every count-kernel launch, batch by batch: a batch's events are read once they have
     // completed (harvest_timing), possibly several batches later -- a caller that never synchronises this ctx (the
     // multi-GPU step: count, pack, reset) still gets every batch's kernel time into kernel_ms_lifetime
-    struct TimedBatch { std::vector<hipEvent_t> ev; int algo = 0; u64 n_bases = 0; };
+    struct TimedBatch { std::vector<hipEvent_t> ev; int algo = 0; u64 n_bases = 0; u32 count_launches = 0; };
     std::deque<TimedBatch> tb;                // batches whose events have not been read yet (front = oldest)
     // KMC_ALGO_AUTO chooses by MEASURED cost: kernel milliseconds per base of this ctx's recent walk-path batches (walk
     // kernel + (k+16)-mer unfold + the table merge at finalize) and sort-path batches (< 0: not measured yet)
@@ -935,6 +935,7 @@ int run_sort_path(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 
         if (rc) return rc;
         rc = launch_end(c);
         if (rc) return rc;
+        if (!c->tb.empty()) c->tb.back().count_launches++;
         c->acc_n += n;
     }
     c->pending = true;
@@ -1416,6 +1417,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                     if (rc) return rc;
                 }
                 c->walk_ws_clean = true;
+                if (!c->tb.empty()) c->tb.back().count_launches++;
                 c->memo_parity ^= 1;
                 c->pending = true;
                 done += take;
@@ -1515,7 +1517,10 @@ void harvest_timing(kmc_ctx* c) {
             c->st.launches_lifetime += b.size() / 2;
             // what this data source costs on the path it took (KMC_ALGO_AUTO's choice between the walk and the sort path)
             const kmc_ctx::TimedBatch& tbk = c->tb.front();
-            if (tbk.n_bases >= (1u << 24)) {   // (small batches are launch overhead, not a rate)
+            // (a rate sample = a large batch that went out in ONE count launch: small batches are launch overhead, and the
+            //  first batch on a new source -- no history: a ramp of launches with polls in between, a memo still learning -- is not
+            //  what later batches cost)
+            if (tbk.n_bases >= (1u << 26) && tbk.count_launches == 1) {
                 const double per = sum / (double)tbk.n_bases;
                 double* dst = tbk.algo == KMC_ALGO_WALK ? &c->walk_ms_per_base : (tbk.algo == KMC_ALGO_SORT ? &c->sort_ms_per_base : nullptr);
                 if (dst) *dst = *dst < 0 ? per : 0.5 * (*dst + per);

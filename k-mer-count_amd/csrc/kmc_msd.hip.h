@@ -433,6 +433,13 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
     }
 }
 
+#ifdef KMC_LEAF_STAMPS
+// diagnostic build only (tools/leaf_stamps.py): cycles per phase of the leaf kernel, summed over all workgroups (thread 0's clock)
+__device__ unsigned long long kmc_leaf_stamps[16];
+#define LEAF_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&kmc_leaf_stamps[i], now_ - t_prev_); t_prev_ = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define LEAF_STAMP(i) do { } while (0)
+#endif
 // Per range: move every key (and weight) to its child's span in the other buffer.  A tile of keys is
 // grouped by digit in LDS first (rank within the tile from one returning LDS add per key), then
 // written out in that order: consecutive lanes write consecutive addresses of one child, so a child
@@ -515,10 +522,14 @@ void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* _
 #pragma unroll
     for (int e = 0; e < PER; ++e) { nlo[e] = 0; nhi[e] = 0; nw[e] = 0; }
     load_tile(0, min((u32)TILE, n));
+#ifdef KMC_LEAF_STAMPS
+    unsigned long long t_prev_ = __builtin_amdgcn_s_memtime();
+#endif
     for (u32 t0 = 0; t0 < n; t0 += TILE) {
         const u32 tn = min((u32)TILE, n - t0);
         for (u32 d = tid; d < KMC_MSD_NB; d += 1024) L.cnt[d] = 0;
         __syncthreads();
+        LEAF_STAMP(8);    // (scatter) waiting for the stores of the tile before / tile entry
         // 1. my keys, their digits and their ranks within the tile
         u64 mlo[PER], mhi[PER], mw[PER];
         u32 md[PER];  // digit (11 bits) | rank within the tile << 11; ~0: no key  (one register per key: at 16 keys
@@ -534,6 +545,7 @@ void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* _
         }
         if (t0 + TILE < n) load_tile(t0 + TILE, min((u32)TILE, n - t0 - TILE));  // (block-uniform) next tile's loads go out now and land during steps 2-4
         __syncthreads();
+        LEAF_STAMP(9);    // (scatter) digits + rank atomics (incl. waiting for this tile's loads)
         // 2. exclusive prefix of the tile's digit counts (thread d <-> digit d; the filler bin comes last)
         {
             const u32 c = L.cnt[tid];
@@ -551,6 +563,7 @@ void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* _
             if (tid == 1023) L.cnt[KMC_MSD_ND] = off + c;  // fillers sit behind every key and are not written out
         }
         __syncthreads();
+        LEAF_STAMP(10);   // (scatter) prefix
         // 3. into LDS, grouped by digit
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
@@ -562,6 +575,7 @@ void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* _
             }
         }
         __syncthreads();
+        LEAF_STAMP(11);   // (scatter) LDS scatter
         // 4. out, in LDS order
         const u32 n_keys = L.cnt[KMC_MSD_ND];  // keys of the tile that are not filler
 #pragma unroll
@@ -577,6 +591,7 @@ void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* _
             }
         }
         __syncthreads();
+        LEAF_STAMP(12);   // (scatter) out
     }
 }
 
@@ -604,13 +619,6 @@ __global__ void kmc_msd_order_kernel(const MsdTerm* __restrict__ term, u32 n_ter
 // final dense place at once.  Exact, but 11.7 instead of 7.9 ms per GB: a leaf finishes together with the ~1,800 leaves
 // in flight around it, so the nearest inclusive prefix is a thousand terminals back and every workgroup ends up
 // waiting for the slowest of its neighbours -- profiles/r03_sort_leaf_variants.txt.)
-#ifdef KMC_LEAF_STAMPS
-// diagnostic build only (tools/leaf_stamps.py): cycles per phase of the leaf kernel, summed over all workgroups (thread 0's clock)
-__device__ unsigned long long kmc_leaf_stamps[16];
-#define LEAF_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&kmc_leaf_stamps[i], now_ - t_prev_); t_prev_ = __builtin_amdgcn_s_memtime(); } } while (0)
-#else
-#define LEAF_STAMP(i) do { } while (0)
-#endif
 template <int KW, bool WEIGHTS, int CAPV, int SCRV> struct MsdLeafLds {
     static constexpr int CAP = CAPV;   // leaf capacity (KMC_MSD_LEAF1 / LEAF2 / LEAF2W; two-word sorts also run with 1024)
     // ONE image of the leaf (the keys come in through registers: with a second image a one-word leaf took

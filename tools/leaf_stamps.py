@@ -20,4 +20,9 @@ with kmc.KmerCounter(k=k, algo=kmc.ALGO_SORT) as kc:
         L.kmc_debug_leaf_stamps(out, 1)
 names = ["load keys", "min/max", "count + prefix", "cursor + scatter", "rank count + rewrite", "large sub-buckets", "run heads", "pairs out"]
 v = np.array(list(out)[:8], dtype=np.float64)
-for nm, x in zip(names, v): print(f"{nm:24s} {x / v.sum() * 100:5.1f} %   {x / 1e6:10.1f} Mcycles")
+print("leaf kernel")
+for nm, x in zip(names, v): print(f"  {nm:24s} {x / v.sum() * 100:5.1f} %   {x / 1e6:10.1f} Mcycles")
+names = ["tile entry", "digits + rank atomics (+ wait loads)", "prefix", "LDS scatter", "out (stores)"]
+v = np.array(list(out)[8:13], dtype=np.float64)
+print("scatter kernel")
+for nm, x in zip(names, v): print(f"  {nm:38s} {x / v.sum() * 100:5.1f} %   {x / 1e6:10.1f} Mcycles")
