@@ -402,6 +402,12 @@ int grid_for(const kmc_ctx* c, u64 n, int threads) {
     return (int)blocks;
 }
 
+// workgroups of kmc_reset_kernel: every one of them draws a ticket from ONE word at the end (the counters are cleared behind
+// the last), so few of them while the table is small enough to be cleared by few
+int reset_grid(const kmc_ctx* c) {
+    return c->tab.cap <= (16ull << 20) ? 256 : (int)std::min<u64>(c->tab.cap >> 14, 2048);
+}
+
 template <typename F1, typename F2>
 auto kw_dispatch(int KW, F1 f1, F2 f2) { return KW == 1 ? f1() : f2(); }
 
@@ -999,9 +1005,9 @@ int recover_overflow(kmc_ctx* c) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
         }
         if (n_snap == ~0ull) return fail(c, KMC_ERR_CAPACITY, "count table and spill area exhausted and the table could not be restored; raise capacity_hint");
-        const int grid = grid_for(c, c->tab.cap, 256);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
-        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
+        const int grid = reset_grid(c);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
+        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
         ctr[KMC_CTR_OCCUPIED] = 0;  // (the merge below claims the slots again and counts them)
         HIPCHK(c, hipMemcpyAsync(c->d_counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, c->stream));
         if (n_snap) {
@@ -1044,9 +1050,9 @@ int recover_overflow(kmc_ctx* c) {
 // and 60 GB of buffers less).  ctr0 = the device counters at the start of the batch.
 int drop_batch_from_table(kmc_ctx* c, const u64* ctr0) {
     GTable g = gtable_of(c, c->tab);
-    const int grid = grid_for(c, c->tab.cap, 256);
-    if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
-    else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
+    const int grid = reset_grid(c);
+    if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
+    else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->d_counters, ctr0, KMC_CTR_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     { int rs = sk_clear(c); if (rs) return rs; }
@@ -1096,7 +1102,7 @@ int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
 
 void harvest_timing(kmc_ctx* c);
 // the two kernels behind a walk launch that logged (kmc_sklog.hip.h)
-int launch_sklog(kmc_ctx* c, const SkLog& lg, u32 wgrid, u32 slices, u32 bin_cap) {
+int launch_sklog(kmc_ctx* c, const SkLog& lg, u32 wgrid, u32 bin_cap) {
     GTable g = gtable_of(c, c->tab);
     const bool canon = c->cfg.canonical != 0;
     const int k = c->cfg.k;
@@ -1106,7 +1112,7 @@ int launch_sklog(kmc_ctx* c, const SkLog& lg, u32 wgrid, u32 slices, u32 bin_cap
     do {                                                                                                                                     \
         static std::atomic<unsigned long long> attr{0};                                                                                      \
         if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_sklog_consume_kernel<KWV, CAN, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SklogTable<WV>)); \
-        hipLaunchKernelGGL((kmc_sklog_partition_kernel<KWV, CAN, WV>), dim3(wgrid * slices), dim3(1024), 0, c->stream, (const u64*)lg.rec, (const u32*)lg.count, lg.cap_wg, slices, bins, cur, bin_cap, k, g); \
+        hipLaunchKernelGGL((kmc_sklog_partition_kernel<KWV, CAN, WV>), dim3(wgrid), dim3(1024), 0, c->stream, (const u64*)lg.rec, (const u32*)lg.count, lg.cap_wg, bins, cur, bin_cap, k, g); \
         hipLaunchKernelGGL((kmc_sklog_consume_kernel<KWV, CAN, WV>), dim3(KMC_SKLOG_BINS), dim3(1024), sizeof(SklogTable<WV>), c->stream, (const u64*)bins, (const u32*)cur, bin_cap, k, g); \
     } while (0)
     if (lg.words == 2) {
@@ -1371,7 +1377,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 // the log of the steps that fall off the LDS memo (kmc_sklog.hip.h), sized for the worst case -- every step of the
                 // launch -- up to 12 GiB; a workgroup whose span is full goes on with (k+16)-mer table updates
                 SkLog lg{};
-                u32 lg_slices = 0, lg_bin_cap = 0;
+                u32 lg_bin_cap = 0;
                 const int wgrid = kmc_walk_grid(take, c->n_cu);
                 if (c->sklog_on && skt.key_lo && !getenv("KMC_NO_SKLOG")) {
                     const u32 words = c->cfg.k > KMC_SK_MAX_K ? 4u : 2u;
@@ -1386,7 +1392,6 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                         HIPCHK(c, hipMemsetAsync(c->lg_count.p, 0, (size_t)c->n_cu * sizeof(u32), c->stream));
                         HIPCHK(c, hipMemsetAsync(c->lg_cursor.p, 0, KMC_SKLOG_BINS * sizeof(u32), c->stream));
                         lg = SkLog{(u64*)c->lg_rec.p, (u32*)c->lg_count.p, (u32)cap, words};
-                        lg_slices = (u32)((cap + KMC_SKLOG_SLICE - 1) / KMC_SKLOG_SLICE);
                         lg_bin_cap = (u32)bin_cap;
                     } else {
                         c->err[0] = 0;   // (no memory for a log: the launch runs with table updates, as before)
@@ -1411,7 +1416,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 if (lg.rec) {   // count what the launch logged: partition by hash, LDS tables, one unfold per distinct (k+16)-mer
                     rc = launch_begin(c);
                     if (rc) return rc;
-                    rc = launch_sklog(c, lg, (u32)wgrid, lg_slices, lg_bin_cap);
+                    rc = launch_sklog(c, lg, (u32)wgrid, lg_bin_cap);
                     if (rc) return rc;
                     rc = launch_end(c);
                     if (rc) return rc;
@@ -1652,7 +1657,7 @@ static int kmc_reset_impl(kmc_ctx* c) {
         c->drained = false;
         c->sk_dirty = false;   // (kmc_finalize_async queued the unfold in front of its kernel)
         GTable g = gtable_of(c, c->tab);
-        int grid = grid_for(c, c->tab.cap, 256);
+        const int grid = reset_grid(c);
         if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
         else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
         HIPCHK(c, hipGetLastError());
@@ -1665,9 +1670,9 @@ static int kmc_reset_impl(kmc_ctx* c) {
     } else {
         if (c->sk_dirty) { int r = flush_sk(c); if (r) return r; }  // (empties the (k+16)-mer table; its counts go with the table)
         GTable g = gtable_of(c, c->tab);
-        int grid = grid_for(c, c->tab.cap, 256);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
-        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u32*)nullptr);
+        const int grid = reset_grid(c);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
+        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
         HIPCHK(c, hipGetLastError());
         c->fin_parity = 0;
     }

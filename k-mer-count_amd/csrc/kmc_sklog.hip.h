@@ -2,9 +2,9 @@
 // that fell off the LDS memo, one record per step, in per-workgroup spans.  Grouping equal records is the reference's
 // grouping step once more (k-mer-count/src/main.rs:84,87: sort, then equal lines), done here without a sort and
 // without a global hash table:
-//   1. kmc_sklog_partition_kernel  a record goes to one of 1024 BINS by a hash of all its words: per slice of 4096
-//                                  records an LDS histogram, one returning global atomic per non-empty bin to reserve
-//                                  the slice's room there, then the records are stored (equal records meet in one bin);
+//   1. kmc_sklog_partition_kernel  a record goes to one of 1024 BINS by a hash of all its words: per span of the log an
+//                                  LDS histogram, one returning global atomic per non-empty bin to reserve the span's
+//                                  room there, then the records are stored (equal records meet in one bin);
 //   2. kmc_sklog_consume_kernel    one workgroup per bin counts its records in an LDS hash table (4096 entries: a bin of
 //                                  the plateau inputs holds a few dozen to a few thousand distinct records) and unfolds
 //                                  every distinct (k+16)-mer ONCE: its 16 k-mers receive the count in the count table.
@@ -16,7 +16,6 @@
 #include "kmc_walk.hip.h"
 
 #define KMC_SKLOG_BINS 1024
-#define KMC_SKLOG_SLICE 4096     // records per partition workgroup (4 per thread)
 #define KMC_SKLOG_TCAP 4096      // LDS table slots of a consume workgroup
 
 // the 16 k-mers of one (k+16)-mer {top, mid, lo}, each + cnt (what kmc_sk_unfold_kernel does per table entry)
@@ -29,56 +28,69 @@ __device__ __forceinline__ void sklog_unfold_one(const GTable& g, int k, u64 top
     walk_gadd<KW, CANON>(g, km, k, cnt);
 }
 
+// One workgroup per span of the log (= per workgroup of the walk launch), two passes over its records: count them per bin
+// in LDS, reserve the span's room in every bin with ONE returning global atomic per bin, then store the records.  (The first
+// version reserved per slice of 4096 records: 7 M returning atomics on the same 1024 cursors per GB of reads, 12.5 ms.)
 template <int KW, bool CANON, int W>
 __global__ __launch_bounds__(1024)
-void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restrict__ count, u32 cap_wg, u32 slices_per_wg,
+void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restrict__ count, u32 cap_wg,
                                 u64* __restrict__ bins, u32* __restrict__ bin_cursor, u32 bin_cap, int k, GTable g) {
     __shared__ u32 cnt[KMC_SKLOG_BINS], gbase[KMC_SKLOG_BINS];
     typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-    const u32 w = blockIdx.x / slices_per_wg, sl = blockIdx.x % slices_per_wg, tid = threadIdx.x;
+    const u32 w = blockIdx.x, tid = threadIdx.x;
     const u32 n = min(count[w], cap_wg);
-    const u32 s0 = sl * KMC_SKLOG_SLICE;
-    if (s0 >= n) return;
-    const u32 m = min((u32)KMC_SKLOG_SLICE, n - s0);
+    if (!n) return;
+    const u64* const span = rec + (size_t)w * cap_wg * W;
+    auto bin_of = [&](u64x2_t a, u64x2_t b) -> u32 {
+        const u64 h = W == 4 ? kmc_hash_key<3>(b.x, a.x, a.y) : kmc_hash_key<2>(a.y, a.x);
+        return (u32)(h >> (64 - 10));
+    };
     cnt[tid] = 0;
     __syncthreads();
-    constexpr int PER = KMC_SKLOG_SLICE / 1024;
-    u64x2_t a[PER], b[PER];
-    u32 dr[PER];   // bin | rank << 10
+    constexpr int U = 4;   // records per thread and trip (independent loads)
+    for (u32 i0 = 0; i0 < n; i0 += 1024u * U) {
+        u64x2_t a[U], b[U];
 #pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        const u32 i = tid + 1024u * e;
-        dr[e] = ~0u;
-        if (i < m) {
-            const u64x2_t* r = reinterpret_cast<const u64x2_t*>(rec + ((size_t)w * cap_wg + s0 + i) * W);
-            a[e] = r[0];
-            if (W == 4) b[e] = r[1];
-            const u64 h = W == 4 ? kmc_hash_key<3>(b[e].x, a[e].x, a[e].y) : kmc_hash_key<2>(a[e].y, a[e].x);
-            const u32 d = (u32)(h >> (64 - 10));
-            dr[e] = d | (atomicAdd(&cnt[d], 1u) << 10);
+        for (int u = 0; u < U; ++u) {
+            const u32 i = i0 + tid + 1024u * u;
+            a[u] = u64x2_t{0, 0}; b[u] = u64x2_t{0, 0};
+            if (i < n) { const u64x2_t* r = reinterpret_cast<const u64x2_t*>(span + (size_t)i * W); a[u] = r[0]; if (W == 4) b[u] = r[1]; }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (i0 + tid + 1024u * u < n) atomicAdd(&cnt[bin_of(a[u], b[u])], 1u);
     }
     __syncthreads();
     {
         const u32 c = cnt[tid];
         gbase[tid] = c ? atomicAdd(&bin_cursor[tid], c) : 0u;
+        cnt[tid] = 0;   // (now the span's running position inside its reservation)
     }
     __syncthreads();
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
+    for (u32 i0 = 0; i0 < n; i0 += 1024u * U) {
+        u64x2_t a[U], b[U];
 #pragma unroll
-    for (int e = 0; e < PER; ++e) {
-        if (dr[e] != ~0u) {
-            const u32 d = dr[e] & 1023u, pos = gbase[d] + (dr[e] >> 10);
-            if (pos < bin_cap) {
-                u64x2_t* o = reinterpret_cast<u64x2_t*>(bins + ((size_t)d * bin_cap + pos) * W);
-                o[0] = a[e];
-                if (W == 4) o[1] = b[e];
-            } else {
-                // a bin past its capacity (1.25 x the even share of the largest possible log: only a log dominated by a
-                // few records gets here): the record's 16 k-mers at once
-                for (u32 j = 0; j < 16; ++j) sklog_unfold_one<KW, CANON>(g, k, W == 4 ? b[e].x : 0ull, a[e].y, a[e].x, j, 1, mask_hi, mask_lo);
+        for (int u = 0; u < U; ++u) {
+            const u32 i = i0 + tid + 1024u * u;
+            a[u] = u64x2_t{0, 0}; b[u] = u64x2_t{0, 0};
+            if (i < n) { const u64x2_t* r = reinterpret_cast<const u64x2_t*>(span + (size_t)i * W); a[u] = r[0]; if (W == 4) b[u] = r[1]; }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (i0 + tid + 1024u * u < n) {
+                const u32 d = bin_of(a[u], b[u]);
+                const u32 pos = gbase[d] + atomicAdd(&cnt[d], 1u);
+                if (pos < bin_cap) {
+                    u64x2_t* o = reinterpret_cast<u64x2_t*>(bins + ((size_t)d * bin_cap + pos) * W);
+                    o[0] = a[u];
+                    if (W == 4) o[1] = b[u];
+                } else {
+                    // a bin past its capacity (1.25 x the even share of the largest possible log: only a log dominated by a
+                    // few records gets here): the record's 16 k-mers at once
+                    for (u32 j = 0; j < 16; ++j) sklog_unfold_one<KW, CANON>(g, k, W == 4 ? b[u].x : 0ull, a[u].y, a[u].x, j, 1, mask_hi, mask_lo);
+                }
             }
         }
     }

@@ -51,24 +51,28 @@ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_cnt, u64* o
     if (lane == 0 && sum) atomicAdd((unsigned long long*)&g.counters[c_sum], sum);
 }
 
-// kmc_reset in one launch: every slot empty, every counter zero.
-// done != nullptr: the table may already BE empty (a finalize queued without waiting, kmc_finalize_async, drains it
-// when it succeeds -- the host cannot know): a table whose counters say "nothing claimed, nothing spilled" is left
-// alone.  Every workgroup must see the SAME counters, so they are cleared by the workgroup that draws the last
+// kmc_reset in one launch: every slot empty, every counter zero.  The device decides how: a table whose claimed
+// slots are all listed (at most KMC_OCC_LIST_CAP keys, nothing spilled: every table of generator-style input) is emptied
+// through the list -- a few thousand stores instead of a 16 MB memset --, an empty table is left alone (a finalize queued
+// without waiting, kmc_finalize_async, drains it when it succeeds and the host cannot know), anything else is cleared
+// slot by slot.  Every workgroup must see the SAME counters, so they are cleared by the workgroup that draws the last
 // ticket of *done (zero between launches), after all have read them.
 template <int KW>
-__global__ void kmc_reset_kernel(GTable g, u32* done = nullptr) {
+__global__ void kmc_reset_kernel(GTable g, u32* done) {
     const u64 cap = g.capmask + 1;
-    const bool skip = done && g.counters[KMC_CTR_OCCUPIED] == 0 && g.counters[KMC_CTR_SPILL] == 0;
-    if (!skip) {
+    const u64 n = g.counters[KMC_CTR_OCCUPIED];
+    const bool listed = n <= g.occ_list_cap && g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0;
+    if (listed) {
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+            const u64 s = g.occ_list[i];
+            if (KW == 2) { g.key_hi[s] = KMC_EMPTY64; g.key_lo[s] = 0; } else g.key_lo[s] = KMC_EMPTY64;
+            g.count[s] = 0;
+        }
+    } else {
         for (u64 s = (u64)blockIdx.x * blockDim.x + threadIdx.x; s < cap; s += (u64)gridDim.x * blockDim.x) {
             if (KW == 2) { g.key_hi[s] = KMC_EMPTY64; g.key_lo[s] = 0; } else g.key_lo[s] = KMC_EMPTY64;
             g.count[s] = 0;
         }
-    }
-    if (!done) {
-        if (blockIdx.x == 0 && threadIdx.x < KMC_CTR_N) g.counters[threadIdx.x] = 0;
-        return;
     }
     __shared__ u32 s_last;
     __syncthreads();   // (this workgroup has read the counters)
