@@ -1110,9 +1110,10 @@ int launch_sklog(kmc_ctx* c, const SkLog& lg, u32 wgrid, u32 bin_cap) {
     u32* cur = (u32*)c->lg_cursor.p;
 #define SKLOG_LAUNCH(KWV, CAN, WV)                                                                                                           \
     do {                                                                                                                                     \
-        static std::atomic<unsigned long long> attr{0};                                                                                      \
+        static std::atomic<unsigned long long> attr{0}, attr2{0};                                                                            \
         if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_sklog_consume_kernel<KWV, CAN, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SklogTable<WV>)); \
-        hipLaunchKernelGGL((kmc_sklog_partition_kernel<KWV, CAN, WV>), dim3(wgrid), dim3(1024), 0, c->stream, (const u64*)lg.rec, (const u32*)lg.count, lg.cap_wg, bins, cur, bin_cap, k, g); \
+        if (kmc_attr_once(attr2)) (void)hipFuncSetAttribute((const void*)kmc_sklog_partition_kernel<KWV, CAN, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SklogPartLds<WV>)); \
+        hipLaunchKernelGGL((kmc_sklog_partition_kernel<KWV, CAN, WV>), dim3(wgrid), dim3(1024), sizeof(SklogPartLds<WV>), c->stream, (const u64*)lg.rec, (const u32*)lg.count, lg.cap_wg, bins, cur, bin_cap, k, g); \
         hipLaunchKernelGGL((kmc_sklog_consume_kernel<KWV, CAN, WV>), dim3(KMC_SKLOG_BINS), dim3(1024), sizeof(SklogTable<WV>), c->stream, (const u64*)bins, (const u32*)cur, bin_cap, k, g); \
     } while (0)
     if (lg.words == 2) {

@@ -29,15 +29,33 @@ __device__ __forceinline__ void sklog_unfold_one(const GTable& g, int k, u64 top
 }
 
 // One workgroup per span of the log (= per workgroup of the walk launch), two passes over its records: count them per bin
-// in LDS, reserve the span's room in every bin with ONE returning global atomic per bin, then store the records.  (The first
-// version reserved per slice of 4096 records: 7 M returning atomics on the same 1024 cursors per GB of reads, 12.5 ms.)
+// in LDS and reserve the span's room in every bin with ONE returning global atomic per bin; then tile by tile (128 KB of
+// records) group the tile by bin in LDS and write it out in that order, so that consecutive lanes store consecutive
+// records of one bin -- runs of 128 bytes instead of single records.
+// (Version 1 reserved per slice of 4096 records: 7 M returning atomics on the same 1024 cursors per GB of reads.  Version 2
+// reserved per span but stored every record straight from its lane, 64 lanes into 64 different bins: 19 ms per GB of reads
+// for 0.45 GB of records -- with or without the LDS rank atomics, 0.14 ms without the stores: single 16-byte stores
+// scattered over a thousand regions are what the memory system does worst.  profiles/r03_sklog_partition_variants.txt)
+template <int W> struct SklogPartLds {
+    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    static constexpr int TILE = W == 2 ? 8192 : 4096;
+    u64x2_t a[TILE];
+    u64x2_t b[W == 4 ? TILE : 1];
+    u32 cnt[KMC_SKLOG_BINS];     // records of the tile per bin, then their exclusive prefix
+    u32 dst[KMC_SKLOG_BINS];     // position in the bin of the tile's first record of that bin, minus its LDS index
+    u32 gpos[KMC_SKLOG_BINS];    // the span's running position in every bin
+    u32 wsum[16];
+};
 template <int KW, bool CANON, int W>
 __global__ __launch_bounds__(1024)
 void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restrict__ count, u32 cap_wg,
                                 u64* __restrict__ bins, u32* __restrict__ bin_cursor, u32 bin_cap, int k, GTable g) {
-    __shared__ u32 cnt[KMC_SKLOG_BINS], gbase[KMC_SKLOG_BINS];
+    extern __shared__ __align__(16) unsigned char sklog_smem[];
+    typedef SklogPartLds<W> LT;
+    LT& L = *reinterpret_cast<LT*>(sklog_smem);
     typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-    const u32 w = blockIdx.x, tid = threadIdx.x;
+    constexpr int TILE = LT::TILE, PER = TILE / 1024;
+    const u32 w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const u32 n = min(count[w], cap_wg);
     if (!n) return;
     const u64* const span = rec + (size_t)w * cap_wg * W;
@@ -45,51 +63,91 @@ void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restri
         const u64 h = W == 4 ? kmc_hash_key<3>(b.x, a.x, a.y) : kmc_hash_key<2>(a.y, a.x);
         return (u32)(h >> (64 - 10));
     };
-    cnt[tid] = 0;
+    // pass 1: the span's records per bin; one reservation per bin
+    L.cnt[tid] = 0;
     __syncthreads();
-    constexpr int U = 4;   // records per thread and trip (independent loads)
-    for (u32 i0 = 0; i0 < n; i0 += 1024u * U) {
-        u64x2_t a[U], b[U];
+    for (u32 i0 = 0; i0 < n; i0 += 1024u * 4) {
+        u64x2_t a[4], b[4];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
+        for (int u = 0; u < 4; ++u) {
             const u32 i = i0 + tid + 1024u * u;
             a[u] = u64x2_t{0, 0}; b[u] = u64x2_t{0, 0};
             if (i < n) { const u64x2_t* r = reinterpret_cast<const u64x2_t*>(span + (size_t)i * W); a[u] = r[0]; if (W == 4) b[u] = r[1]; }
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) if (i0 + tid + 1024u * u < n) atomicAdd(&cnt[bin_of(a[u], b[u])], 1u);
+        for (int u = 0; u < 4; ++u) if (i0 + tid + 1024u * u < n) atomicAdd(&L.cnt[bin_of(a[u], b[u])], 1u);
     }
     __syncthreads();
     {
-        const u32 c = cnt[tid];
-        gbase[tid] = c ? atomicAdd(&bin_cursor[tid], c) : 0u;
-        cnt[tid] = 0;   // (now the span's running position inside its reservation)
+        const u32 c = L.cnt[tid];
+        L.gpos[tid] = c ? atomicAdd(&bin_cursor[tid], c) : 0u;
     }
-    __syncthreads();
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
-    for (u32 i0 = 0; i0 < n; i0 += 1024u * U) {
-        u64x2_t a[U], b[U];
+    // pass 2: tile by tile through LDS
+    for (u32 t0 = 0; t0 < n; t0 += TILE) {
+        const u32 tn = min((u32)TILE, n - t0);
+        __syncthreads();   // (gpos written; the previous tile read out)
+        L.cnt[tid] = 0;
+        __syncthreads();
+        u64x2_t a[PER], b[PER];
+        u32 dr[PER];   // bin | rank within the tile << 10
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const u32 i = i0 + tid + 1024u * u;
-            a[u] = u64x2_t{0, 0}; b[u] = u64x2_t{0, 0};
-            if (i < n) { const u64x2_t* r = reinterpret_cast<const u64x2_t*>(span + (size_t)i * W); a[u] = r[0]; if (W == 4) b[u] = r[1]; }
+        for (int e = 0; e < PER; ++e) {
+            const u32 i = tid + 1024u * e;
+            dr[e] = ~0u;
+            a[e] = u64x2_t{0, 0}; b[e] = u64x2_t{0, 0};
+            if (i < tn) {
+                const u64x2_t* r = reinterpret_cast<const u64x2_t*>(span + (size_t)(t0 + i) * W);
+                a[e] = r[0];
+                if (W == 4) b[e] = r[1];
+                const u32 d = bin_of(a[e], b[e]);
+                dr[e] = d | (atomicAdd(&L.cnt[d], 1u) << 10);
+            }
         }
+        __syncthreads();
+        {   // exclusive prefix of the tile's bin counts (thread d <-> bin d)
+            const u32 c = L.cnt[tid];
+            u32 inc = c;
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (i0 + tid + 1024u * u < n) {
-                const u32 d = bin_of(a[u], b[u]);
-                const u32 pos = gbase[d] + atomicAdd(&cnt[d], 1u);
+            for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+            if (lane == 63) L.wsum[wv] = inc;
+            __syncthreads();
+            u32 base = 0;
+            for (u32 x = 0; x < wv; ++x) base += L.wsum[x];
+            const u32 off = base + inc - c;
+            L.cnt[tid] = off;
+            L.dst[tid] = L.gpos[tid] - off;
+            L.gpos[tid] += c;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            if (dr[e] != ~0u) {
+                const u32 p = L.cnt[dr[e] & 1023u] + (dr[e] >> 10);
+                L.a[p] = a[e];
+                if (W == 4) L.b[p] = b[e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const u32 p = tid + 1024u * e;
+            if (p < tn) {
+                const u64x2_t ra = L.a[p];
+                u64x2_t rb = u64x2_t{0, 0};
+                if (W == 4) rb = L.b[p];
+                const u32 d = bin_of(ra, rb);
+                const u32 pos = L.dst[d] + p;
                 if (pos < bin_cap) {
                     u64x2_t* o = reinterpret_cast<u64x2_t*>(bins + ((size_t)d * bin_cap + pos) * W);
-                    o[0] = a[u];
-                    if (W == 4) o[1] = b[u];
+                    o[0] = ra;
+                    if (W == 4) o[1] = rb;
                 } else {
                     // a bin past its capacity (1.25 x the even share of the largest possible log: only a log dominated by a
                     // few records gets here): the record's 16 k-mers at once
-                    for (u32 j = 0; j < 16; ++j) sklog_unfold_one<KW, CANON>(g, k, W == 4 ? b[u].x : 0ull, a[u].y, a[u].x, j, 1, mask_hi, mask_lo);
+                    for (u32 j = 0; j < 16; ++j) sklog_unfold_one<KW, CANON>(g, k, W == 4 ? rb.x : 0ull, ra.y, ra.x, j, 1, mask_hi, mask_lo);
                 }
             }
         }
