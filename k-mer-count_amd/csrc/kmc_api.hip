@@ -1101,20 +1101,24 @@ int build_vreads(kmc_ctx* c, const u64* d_offsets, u64 n_reads, u64* n_v_out) {
 }
 
 void harvest_timing(kmc_ctx* c);
-// the two kernels behind a walk launch that logged (kmc_sklog.hip.h)
-int launch_sklog(kmc_ctx* c, const SkLog& lg, u32 wgrid, u32 bin_cap) {
+// the three kernels behind a walk launch that logged (kmc_sklog.hip.h): bin totals, partition, count + unfold
+int launch_sklog(kmc_ctx* c, const SkLog& lg, u32 wgrid) {
     GTable g = gtable_of(c, c->tab);
     const bool canon = c->cfg.canonical != 0;
     const int k = c->cfg.k;
-    u64* bins = (u64*)c->lg_bins.p;
-    u32* cur = (u32*)c->lg_cursor.p;
+    u64* binned = (u64*)c->lg_bins.p;
+    u32* total = (u32*)c->lg_cursor.p;              // [1024] records per bin
+    u32* cur = total + KMC_SKLOG_BINS;              // [1024] reservations so far
+    u32* span_hist = (u32*)c->lg_count.p + c->n_cu; // [wgrid][1024]
 #define SKLOG_LAUNCH(KWV, CAN, WV)                                                                                                           \
     do {                                                                                                                                     \
         static std::atomic<unsigned long long> attr{0}, attr2{0};                                                                            \
         if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_sklog_consume_kernel<KWV, CAN, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SklogTable<WV>)); \
-        if (kmc_attr_once(attr2)) (void)hipFuncSetAttribute((const void*)kmc_sklog_partition_kernel<KWV, CAN, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SklogPartLds<WV>)); \
-        hipLaunchKernelGGL((kmc_sklog_partition_kernel<KWV, CAN, WV>), dim3(wgrid), dim3(1024), sizeof(SklogPartLds<WV>), c->stream, (const u64*)lg.rec, (const u32*)lg.count, lg.cap_wg, bins, cur, bin_cap, k, g); \
-        hipLaunchKernelGGL((kmc_sklog_consume_kernel<KWV, CAN, WV>), dim3(KMC_SKLOG_BINS), dim3(1024), sizeof(SklogTable<WV>), c->stream, (const u64*)bins, (const u32*)cur, bin_cap, k, g); \
+        if (kmc_attr_once(attr2)) (void)hipFuncSetAttribute((const void*)kmc_sklog_partition_kernel<WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SklogPartLds<WV>)); \
+        hipLaunchKernelGGL((kmc_sklog_hist_kernel<WV>), dim3(wgrid), dim3(1024), 0, c->stream, (const u64*)lg.rec, (const u32*)lg.count, lg.cap_wg, span_hist, total); \
+        hipLaunchKernelGGL((kmc_sklog_partition_kernel<WV>), dim3(wgrid), dim3(1024), sizeof(SklogPartLds<WV>), c->stream, (const u64*)lg.rec, (const u32*)lg.count, lg.cap_wg, \
+                           (const u32*)span_hist, (const u32*)total, cur, binned);                                                           \
+        hipLaunchKernelGGL((kmc_sklog_consume_kernel<KWV, CAN, WV>), dim3(KMC_SKLOG_BINS), dim3(1024), sizeof(SklogTable<WV>), c->stream, (const u64*)binned, (const u32*)total, k, g); \
     } while (0)
     if (lg.words == 2) {
         if (c->KW == 1) { if (canon) SKLOG_LAUNCH(1, true, 2); else SKLOG_LAUNCH(1, false, 2); }
@@ -1378,7 +1382,6 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 // the log of the steps that fall off the LDS memo (kmc_sklog.hip.h), sized for the worst case -- every step of the
                 // launch -- up to 12 GiB; a workgroup whose span is full goes on with (k+16)-mer table updates
                 SkLog lg{};
-                u32 lg_bin_cap = 0;
                 const int wgrid = kmc_walk_grid(take, c->n_cu);
                 if (c->sklog_on && skt.key_lo && !getenv("KMC_NO_SKLOG")) {
                     const u32 words = c->cfg.k > KMC_SK_MAX_K ? 4u : 2u;
@@ -1386,14 +1389,13 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                     u64 cap = ((take + wgrid - 1) / wgrid + 1) * 64ull * steps_per_read;
                     cap = std::min<u64>(cap, (12ull << 30) / ((u64)wgrid * words * sizeof(u64)));
                     cap = std::max<u64>(cap, 1024);
-                    const u64 bin_cap = ((u64)wgrid * cap / KMC_SKLOG_BINS) * 5 / 4 + 1024;
-                    if (cap < (1ull << 31) && bin_cap < (1ull << 31) &&
-                        !ensure(c, c->lg_rec, (size_t)wgrid * cap * words * sizeof(u64)) && !ensure(c, c->lg_bins, (size_t)KMC_SKLOG_BINS * bin_cap * words * sizeof(u64)) &&
-                        !ensure(c, c->lg_count, (size_t)c->n_cu * sizeof(u32)) && !ensure(c, c->lg_cursor, KMC_SKLOG_BINS * sizeof(u32))) {
+                    // (the binned copy holds exactly the logged records: the same room as the log; fewer than 2^32 records)
+                    if ((u64)wgrid * cap < (1ull << 32) &&
+                        !ensure(c, c->lg_rec, (size_t)wgrid * cap * words * sizeof(u64)) && !ensure(c, c->lg_bins, (size_t)wgrid * cap * words * sizeof(u64)) &&
+                        !ensure(c, c->lg_count, ((size_t)c->n_cu + (size_t)c->n_cu * KMC_SKLOG_BINS) * sizeof(u32)) && !ensure(c, c->lg_cursor, 2 * KMC_SKLOG_BINS * sizeof(u32))) {
                         HIPCHK(c, hipMemsetAsync(c->lg_count.p, 0, (size_t)c->n_cu * sizeof(u32), c->stream));
-                        HIPCHK(c, hipMemsetAsync(c->lg_cursor.p, 0, KMC_SKLOG_BINS * sizeof(u32), c->stream));
+                        HIPCHK(c, hipMemsetAsync(c->lg_cursor.p, 0, 2 * KMC_SKLOG_BINS * sizeof(u32), c->stream));
                         lg = SkLog{(u64*)c->lg_rec.p, (u32*)c->lg_count.p, (u32)cap, words};
-                        lg_bin_cap = (u32)bin_cap;
                     } else {
                         c->err[0] = 0;   // (no memory for a log: the launch runs with table updates, as before)
                     }
@@ -1417,7 +1419,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 if (lg.rec) {   // count what the launch logged: partition by hash, LDS tables, one unfold per distinct (k+16)-mer
                     rc = launch_begin(c);
                     if (rc) return rc;
-                    rc = launch_sklog(c, lg, (u32)wgrid, lg_bin_cap);
+                    rc = launch_sklog(c, lg, (u32)wgrid);
                     if (rc) return rc;
                     rc = launch_end(c);
                     if (rc) return rc;

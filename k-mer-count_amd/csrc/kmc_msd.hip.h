@@ -1120,7 +1120,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     u32 hmask = 0;          // bit e: my element of slab e is a run head
     u32 hpre[NSLAB];        // heads of lower lanes of my wave in slab e
     u32* const stot = L.big;   // [NSLAB][4] heads per (slab, wave) (the list of large sub-buckets is dead by now)
-    static_assert(sizeof(L.big) >= NSLAB * 4 * sizeof(u32), "head totals do not fit");
+    static_assert(sizeof(L.big) >= (NSLAB * 4 + 1) * sizeof(u32), "head totals do not fit");
 #pragma unroll
     for (int e = 0; e < NSLAB; ++e) {
         const u32 i = tid + KMC_MSD_THREADS * e;
@@ -1132,17 +1132,23 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
         if (lane == 0) stot[e * 4 + wv] = (u32)__popcll(m);
     }
     __syncthreads();   // (every element has been compared: the counters under hidx may be overwritten)
-    u32 run = 0, n_heads = 0;
+    u32 n_heads = 0;
     {
-        u32 my_base[NSLAB];
+        // exclusive prefix of the NSLAB x 4 totals by one wave (the other waves wait at the barrier), then every thread
+        // picks up its NSLAB bases
+        static_assert(NSLAB * 4 <= 64, "one wave scans the head totals");
+        if (wv == 0) {
+            const u32 v = lane < NSLAB * 4 ? stot[lane] : 0u;
+            u32 inc = v;
 #pragma unroll
-        for (int e = 0; e < NSLAB; ++e) {
-#pragma unroll
-            for (int w = 0; w < 4; ++w) { if (w == (int)wv) my_base[e] = run; run += stot[e * 4 + w]; }
+            for (int o = 1; o < 64; o <<= 1) { const u32 x = __shfl_up(inc, o); if ((int)lane >= o) inc += x; }
+            if (lane < NSLAB * 4) stot[lane] = inc - v;
+            if (lane == NSLAB * 4 - 1) stot[NSLAB * 4] = inc;
         }
-        n_heads = run;
+        __syncthreads();
+        n_heads = stot[NSLAB * 4];
 #pragma unroll
-        for (int e = 0; e < NSLAB; ++e) if (hmask & (1u << e)) hidx[my_base[e] + hpre[e]] = (unsigned short)(tid + KMC_MSD_THREADS * e);
+        for (int e = 0; e < NSLAB; ++e) if (hmask & (1u << e)) hidx[stot[e * 4 + wv] + hpre[e]] = (unsigned short)(tid + KMC_MSD_THREADS * e);
     }
     __syncthreads();
     LEAF_STAMP(6);   // run heads

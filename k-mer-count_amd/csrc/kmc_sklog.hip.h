@@ -2,16 +2,16 @@
 // that fell off the LDS memo, one record per step, in per-workgroup spans.  Grouping equal records is the reference's
 // grouping step once more (k-mer-count/src/main.rs:84,87: sort, then equal lines), done here without a sort and
 // without a global hash table:
-//   1. kmc_sklog_partition_kernel  a record goes to one of 1024 BINS by a hash of all its words: per span of the log an
-//                                  LDS histogram, one returning global atomic per non-empty bin to reserve the span's
-//                                  room there, then the records are stored (equal records meet in one bin);
+//   1. kmc_sklog_hist_kernel +     a record goes to one of 1024 BINS by a hash of all its words: per span of the log an
+//      kmc_sklog_partition_kernel  LDS histogram (bins are sized exactly from the totals), one returning global atomic per
+//                                  non-empty bin to reserve the span's room there, then the records are stored, grouped
+//                                  by bin through LDS (equal records meet in one bin);
 //   2. kmc_sklog_consume_kernel    one workgroup per bin counts its records in an LDS hash table (4096 entries: a bin of
 //                                  the plateau inputs holds a few dozen to a few thousand distinct records) and unfolds
 //                                  every distinct (k+16)-mer ONCE: its 16 k-mers receive the count in the count table.
 // Work per record: one coalesced read, one 16-/32-byte store, one coalesced read, one LDS table update -- against a
-// read-modify-write of three random lines of a table in HBM per step before.  Records that find no room (a bin past its
-// capacity, an LDS table that is full: inputs with millions of distinct (k+16)-mers) are unfolded on the spot, k-mer by
-// k-mer: always exact.
+// read-modify-write of three random lines of a table in HBM per step before.  Records that find no room in a bin's LDS table
+// (inputs with millions of distinct (k+16)-mers) are unfolded on the spot, k-mer by k-mer: always exact.
 #pragma once
 #include "kmc_walk.hip.h"
 
@@ -28,43 +28,45 @@ __device__ __forceinline__ void sklog_unfold_one(const GTable& g, int k, u64 top
     walk_gadd<KW, CANON>(g, km, k, cnt);
 }
 
-// One workgroup per span of the log (= per workgroup of the walk launch), two passes over its records: count them per bin
-// in LDS and reserve the span's room in every bin with ONE returning global atomic per bin; then tile by tile (128 KB of
-// records) group the tile by bin in LDS and write it out in that order, so that consecutive lanes store consecutive
-// records of one bin -- runs of 128 bytes instead of single records.
-// (Version 1 reserved per slice of 4096 records: 7 M returning atomics on the same 1024 cursors per GB of reads.  Version 2
-// reserved per span but stored every record straight from its lane, 64 lanes into 64 different bins: 19 ms per GB of reads
-// for 0.45 GB of records -- with or without the LDS rank atomics, 0.14 ms without the stores: single 16-byte stores
-// scattered over a thousand regions are what the memory system does worst.  profiles/r03_sklog_partition_variants.txt)
-template <int W> struct SklogPartLds {
-    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-    static constexpr int TILE = W == 2 ? 8192 : 4096;
-    u64x2_t a[TILE];
-    u64x2_t b[W == 4 ? TILE : 1];
-    u32 cnt[KMC_SKLOG_BINS];     // records of the tile per bin, then their exclusive prefix
-    u32 dst[KMC_SKLOG_BINS];     // position in the bin of the tile's first record of that bin, minus its LDS index
-    u32 gpos[KMC_SKLOG_BINS];    // the span's running position in every bin
-    u32 wsum[16];
-};
-template <int KW, bool CANON, int W>
+// Bins are sized EXACTLY: kmc_sklog_hist_kernel counts every span's records per bin (LDS histogram; the row is kept, the
+// totals are added up with one global atomic per span and bin), and both later kernels turn the 1024 totals into bin
+// offsets themselves (a 1024-entry scan per workgroup).  The first version gave every bin 1.25 x its even share: the plateau
+// inputs log a few thousand DISTINCT records, each thousands of times, so the bins' loads follow those records' frequencies
+// -- most bins overflowed and their records fell back to sixteen global atomics each.
+// kmc_sklog_partition_kernel: one workgroup per span reserves the span's room in every bin with ONE returning global
+// atomic per bin, then tile by tile (128 KB of records) groups the tile by bin in LDS and writes it out in that order, so
+// that consecutive lanes store consecutive records of one bin -- runs of 128 bytes instead of single records.
+// (Records stored straight from their lanes, 64 lanes into 64 different bins, took 19 ms per GB of reads for 0.45 GB of
+// records; profiles/r03_sklog_partition_variants.txt.)
+template <int W>
+__device__ __forceinline__ u32 sklog_bin_of(unsigned long long ax, unsigned long long ay, unsigned long long bx) {
+    const u64 h = W == 4 ? kmc_hash_key<3>(bx, ax, ay) : kmc_hash_key<2>(ay, ax);
+    return (u32)(h >> (64 - 10));
+}
+// exclusive prefix of the 1024 bin totals: every thread d of a 1024-thread workgroup gets off[d]; *total = their sum
+__device__ __forceinline__ u32 sklog_bin_offsets(const u32* __restrict__ bin_total, u32* wsum /* 16 words of LDS */, u32 tid, u32* total) {
+    const u32 lane = tid & 63, wv = tid >> 6;
+    const u32 c = bin_total[tid];
+    u32 inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    u32 base = 0, all = 0;
+    for (u32 x = 0; x < 16; ++x) { if (x < wv) base += wsum[x]; all += wsum[x]; }
+    if (total) *total = all;
+    return base + inc - c;
+}
+
+template <int W>
 __global__ __launch_bounds__(1024)
-void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restrict__ count, u32 cap_wg,
-                                u64* __restrict__ bins, u32* __restrict__ bin_cursor, u32 bin_cap, int k, GTable g) {
-    extern __shared__ __align__(16) unsigned char sklog_smem[];
-    typedef SklogPartLds<W> LT;
-    LT& L = *reinterpret_cast<LT*>(sklog_smem);
+void kmc_sklog_hist_kernel(const u64* __restrict__ rec, const u32* __restrict__ count, u32 cap_wg, u32* __restrict__ span_hist, u32* __restrict__ bin_total) {
+    __shared__ u32 cnt[KMC_SKLOG_BINS];
     typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-    constexpr int TILE = LT::TILE, PER = TILE / 1024;
-    const u32 w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 w = blockIdx.x, tid = threadIdx.x;
     const u32 n = min(count[w], cap_wg);
-    if (!n) return;
     const u64* const span = rec + (size_t)w * cap_wg * W;
-    auto bin_of = [&](u64x2_t a, u64x2_t b) -> u32 {
-        const u64 h = W == 4 ? kmc_hash_key<3>(b.x, a.x, a.y) : kmc_hash_key<2>(a.y, a.x);
-        return (u32)(h >> (64 - 10));
-    };
-    // pass 1: the span's records per bin; one reservation per bin
-    L.cnt[tid] = 0;
+    cnt[tid] = 0;
     __syncthreads();
     for (u32 i0 = 0; i0 < n; i0 += 1024u * 4) {
         u64x2_t a[4], b[4];
@@ -75,17 +77,42 @@ void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restri
             if (i < n) { const u64x2_t* r = reinterpret_cast<const u64x2_t*>(span + (size_t)i * W); a[u] = r[0]; if (W == 4) b[u] = r[1]; }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (i0 + tid + 1024u * u < n) atomicAdd(&L.cnt[bin_of(a[u], b[u])], 1u);
+        for (int u = 0; u < 4; ++u) if (i0 + tid + 1024u * u < n) atomicAdd(&cnt[sklog_bin_of<W>(a[u].x, a[u].y, b[u].x)], 1u);
     }
     __syncthreads();
-    {
-        const u32 c = L.cnt[tid];
-        L.gpos[tid] = c ? atomicAdd(&bin_cursor[tid], c) : 0u;
+    const u32 c = cnt[tid];
+    span_hist[(size_t)w * KMC_SKLOG_BINS + tid] = c;
+    if (c) atomicAdd(&bin_total[tid], c);
+}
+
+template <int W> struct SklogPartLds {
+    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    static constexpr int TILE = W == 2 ? 8192 : 4096;
+    u64x2_t a[TILE];
+    u64x2_t b[W == 4 ? TILE : 1];
+    u32 cnt[KMC_SKLOG_BINS];     // records of the tile per bin, then their exclusive prefix
+    u32 dst[KMC_SKLOG_BINS];     // record index (in the binned array) of the tile's first record of that bin, minus its LDS index
+    u32 gpos[KMC_SKLOG_BINS];    // the span's running position in every bin (index in the binned array)
+    u32 wsum[16];
+};
+template <int W>
+__global__ __launch_bounds__(1024)
+void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restrict__ count, u32 cap_wg, const u32* __restrict__ span_hist,
+                                const u32* __restrict__ bin_total, u32* __restrict__ bin_cursor, u64* __restrict__ binned) {
+    extern __shared__ __align__(16) unsigned char sklog_smem[];
+    typedef SklogPartLds<W> LT;
+    LT& L = *reinterpret_cast<LT*>(sklog_smem);
+    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    constexpr int TILE = LT::TILE, PER = TILE / 1024;
+    const u32 w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const u32 n = min(count[w], cap_wg);
+    if (!n) return;
+    const u64* const span = rec + (size_t)w * cap_wg * W;
+    {   // the span's room in every bin: bin offset + what earlier reservations took
+        const u32 off = sklog_bin_offsets(bin_total, L.wsum, tid, nullptr);
+        const u32 c = span_hist[(size_t)w * KMC_SKLOG_BINS + tid];
+        L.gpos[tid] = off + (c ? atomicAdd(&bin_cursor[tid], c) : 0u);
     }
-    const int kb = 2 * k;
-    const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
-    const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
-    // pass 2: tile by tile through LDS
     for (u32 t0 = 0; t0 < n; t0 += TILE) {
         const u32 tn = min((u32)TILE, n - t0);
         __syncthreads();   // (gpos written; the previous tile read out)
@@ -102,7 +129,7 @@ void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restri
                 const u64x2_t* r = reinterpret_cast<const u64x2_t*>(span + (size_t)(t0 + i) * W);
                 a[e] = r[0];
                 if (W == 4) b[e] = r[1];
-                const u32 d = bin_of(a[e], b[e]);
+                const u32 d = sklog_bin_of<W>(a[e].x, a[e].y, b[e].x);
                 dr[e] = d | (atomicAdd(&L.cnt[d], 1u) << 10);
             }
         }
@@ -138,17 +165,10 @@ void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restri
                 const u64x2_t ra = L.a[p];
                 u64x2_t rb = u64x2_t{0, 0};
                 if (W == 4) rb = L.b[p];
-                const u32 d = bin_of(ra, rb);
-                const u32 pos = L.dst[d] + p;
-                if (pos < bin_cap) {
-                    u64x2_t* o = reinterpret_cast<u64x2_t*>(bins + ((size_t)d * bin_cap + pos) * W);
-                    o[0] = ra;
-                    if (W == 4) o[1] = rb;
-                } else {
-                    // a bin past its capacity (1.25 x the even share of the largest possible log: only a log dominated by a
-                    // few records gets here): the record's 16 k-mers at once
-                    for (u32 j = 0; j < 16; ++j) sklog_unfold_one<KW, CANON>(g, k, W == 4 ? rb.x : 0ull, ra.y, ra.x, j, 1, mask_hi, mask_lo);
-                }
+                const u32 d = sklog_bin_of<W>(ra.x, ra.y, rb.x);
+                u64x2_t* o = reinterpret_cast<u64x2_t*>(binned + (size_t)(L.dst[d] + p) * W);
+                o[0] = ra;
+                if (W == 4) o[1] = rb;
             }
         }
     }
@@ -164,13 +184,20 @@ template <int W> struct SklogTable {
 
 template <int KW, bool CANON, int W>
 __global__ __launch_bounds__(1024)
-void kmc_sklog_consume_kernel(const u64* __restrict__ bins, const u32* __restrict__ bin_cursor, u32 bin_cap, int k, GTable g) {
+void kmc_sklog_consume_kernel(const u64* __restrict__ binned, const u32* __restrict__ bin_total, int k, GTable g) {
     extern __shared__ __align__(16) unsigned char sklog_smem[];
     SklogTable<W>& T = *reinterpret_cast<SklogTable<W>*>(sklog_smem);
     typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    __shared__ u32 s_wsum[16], s_begin;
     const u32 d = blockIdx.x, tid = threadIdx.x;
-    const u32 n = min(bin_cursor[d], bin_cap);
-    if (!n) return;
+    const u32 n = bin_total[d];
+    if (!n) return;   // (block-uniform)
+    {
+        const u32 off = sklog_bin_offsets(bin_total, s_wsum, tid, nullptr);
+        if (tid == d) s_begin = off;
+        __syncthreads();
+    }
+    const u64* const bin = binned + (size_t)s_begin * W;
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
@@ -184,7 +211,7 @@ void kmc_sklog_consume_kernel(const u64* __restrict__ bins, const u32* __restric
         const bool act = i < n;
         u64 lo = 0, mid = 0, top = 0;
         if (act) {
-            const u64x2_t* r = reinterpret_cast<const u64x2_t*>(bins + ((size_t)d * bin_cap + i) * W);
+            const u64x2_t* r = reinterpret_cast<const u64x2_t*>(bin + (size_t)i * W);
             const u64x2_t a = r[0];
             lo = a.x; mid = a.y;
             if (W == 4) top = r[1].x;
@@ -226,6 +253,7 @@ void kmc_sklog_consume_kernel(const u64* __restrict__ bins, const u32* __restric
         }
         if (direct) {   // no room in the LDS table: this record's 16 k-mers at once
             for (u32 j = 0; j < 16; ++j) sklog_unfold_one<KW, CANON>(g, k, top, mid, lo, j, 1, mask_hi, mask_lo);
+            atomicAdd((unsigned long long*)&g.counters[KMC_CTR_BADBASE], 16ull);
         }
     }
     __syncthreads();
