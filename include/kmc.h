@@ -156,7 +156,7 @@ int kmc_merge_pairs_device(kmc_ctx* ctx, const void* d_key_hi, const void* d_key
  * more batches may be added afterwards (the sorted view is then stale until the next finalize). */
 int kmc_finalize(kmc_ctx* ctx, uint64_t* n_distinct, uint64_t* n_total);
 
-/* kmc_finalize for a pipeline that does not want to wait: the device work of a SMALL table's finalize (at most 32768
+/* kmc_finalize for a pipeline that does not want to wait: the device work of a SMALL table's finalize (at most 131072
  * keys, nothing spilled: every table of generator-style input) is queued on the ctx stream and the call returns.  Behind
  * it in stream order the sorted view is in place (the pointers kmc_export_device last returned stay valid for small
  * tables) and the table is empty; kmc_reset after it launches one small kernel and does not wait either.  The next call
@@ -194,7 +194,7 @@ uint32_t kmc_owner_of(uint64_t key_hi, uint64_t key_lo, uint32_t n_parts);
  * its size in 64-bit words for this ctx's key width.  kmc_pack_slab_device writes this ctx's table
  * into d_slab -- the sorted view after kmc_finalize, otherwise straight from the live table
  * (unsorted; no finalize and no host synchronisation needed first) -- or marks the slab "oversize"
- * when the table has more than slab_entries keys (live table: also more than 32768).  kmc_merge_slabs_device adds, from n_slabs consecutive slabs (the all-gather
+ * when the table has more than slab_entries keys (live table: also more than 131072).  kmc_merge_slabs_device adds, from n_slabs consecutive slabs (the all-gather
  * result), every pair with kmc_owner_of(key, n_parts) == my_part; oversize slabs are skipped and
  * counted in kmc_stats.n_slabs_skipped at the next kmc_finalize (the caller then moves those
  * tables with kmc_partition_device + all-to-all + kmc_merge_pairs_device).  Both calls are

@@ -47,7 +47,11 @@ struct GTable {
     u64  occ_list_cap;
 };
 
-#define KMC_OCC_LIST_CAP 32768  // claimed slots listed (small-table finalize, slab packing, cheap table snapshots)
+// claimed slots listed (small-table finalize, reset through the list, slab packing, cheap table snapshots).  Round 3: 32768 ->
+// 131072: the rank-sort finalize costs n^2 / 64 compares per workgroup-of-16-keys -- 0.13 ms at 67 k keys, about what the
+// general path (compaction + weighted radix sort: 0.8 ms of fixed cost) takes at 131 k -- and the plateau inputs of the
+// cardinality sweep (pools of 32..100 lines: 29 k .. 255 k distinct 31-mers) sit right above the old limit
+#define KMC_OCC_LIST_CAP 131072
 
 __device__ __forceinline__ u64 kmc_mix64(u64 z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

@@ -647,8 +647,10 @@ template <int KW, bool WEIGHTS, int CAPV, int SCRV> struct MsdLeafLds {
     u64 sx[4][2], sy[4][2];
 };
 
+// (one-word keys without weights: seven workgroups per CU fit by LDS; the register allocation is held to that -- 72 VGPRs --
+// so that the memory phases of some leaves overlap the LDS phases of others)
 template <int KW, bool WEIGHTS, int CAPV, int SCRV>
-__global__ __launch_bounds__(KMC_MSD_THREADS)
+__global__ __launch_bounds__(KMC_MSD_THREADS, (KW == 1 && !WEIGHTS) ? 7 : 1)
 void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo0, const u64* __restrict__ w0,
                          const u64* __restrict__ hi1, const u64* __restrict__ lo1, const u64* __restrict__ w1,
                          const MsdTerm* __restrict__ term, u32 n_term, int kb,

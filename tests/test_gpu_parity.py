@@ -294,14 +294,15 @@ def test_device_resident_batches_and_synth(kmc, oracle):
 
 
 def test_small_table_finalize_sizes(kmc):
-    """The rank-sort finalize of small tables at its size boundaries (64 keys per workgroup, 1024
-    threads, rounds of 8192 keys, at most 32768 keys; 32769 takes the weighted radix sort), one- and
-    two-word keys, repeated on the same ctx (the kernel must leave its rank/ticket workspace clean)."""
+    """The rank-sort finalize of small tables at its size boundaries (16 keys per workgroup of 1024 threads, the
+    table through LDS in tiles of 4096 / 2048 keys, at most 131072 keys; 131073 takes the weighted radix sort), one-
+    and two-word keys, repeated on the same ctx (the kernel drains the table and must leave its ticket clean; a
+    table that outgrew the speculative grid is finalized again with the full one)."""
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(55)
     for k in (31, 63):
         with kmc.KmerCounter(k=k) as kc:
-            for n in (1, 2, 63, 64, 65, 127, 1023, 1024, 1025, 3350, 4096, 8191, 8192, 8193, 20000, 32767, 32768, 32769, 70000, 64):
+            for n in (1, 2, 15, 16, 17, 63, 64, 65, 127, 1023, 1024, 1025, 2047, 2048, 2049, 3350, 4096, 4097, 8191, 8192, 8193, 20000, 32767, 32768, 32769, 70000, 131071, 131072, 131073, 200000, 64):
                 lo = rng.integers(0, 2**62, n, dtype=np.uint64)
                 hi = rng.integers(0, 2**60, n, dtype=np.uint64) if k > 31 else np.zeros(n, np.uint64)
                 if k > 31:
