@@ -641,7 +641,7 @@ int flush_sk(kmc_ctx* c) {
 // right after a poll: launch nothing when the poll shows the (k+16)-mer table empty
 int settle_sk_polled(kmc_ctx* c) {
     if (!c->sk_dirty) return KMC_OK;
-    if (!c->h_sk_counters || c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] == 0) { c->sk_dirty = false; return sk_regrow(c); }
+    if (!c->h_sk_counters || c->h_sk_counters[KMC_CTR_KMERS] == 0) { c->sk_dirty = false; return sk_regrow(c); }   // (keys may be there -- they stay across launches -- but no counts are pending)
     return flush_sk(c);
 }
 
@@ -1142,7 +1142,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     // the previous batch's (k+16)-mer counts, if it left any: the counters are as of a poll that came after
     // its last launch (every launch sets `pending`), so an empty table is known to be empty
     {
-        const bool unfolds = c->sk_dirty && c->h_sk_counters && c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] != 0;
+        const bool unfolds = c->sk_dirty && c->h_sk_counters && c->h_sk_counters[KMC_CTR_KMERS] != 0;
         int rc = settle_sk_polled(c);
         if (rc) return rc;
         // the unfold just queued changes the table: the launch planner (and the table it saves in front of a risky
@@ -1797,7 +1797,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     if (rc) return rc;
     if (c->sk_dirty) {
         // the last batch's walk launches may have left counts in the (k+16)-mer table: the poll tells
-        const bool had = c->h_sk_counters && c->h_sk_counters[KMC_CTR_OCCUPIED] + c->h_sk_counters[KMC_CTR_SPILL] != 0;
+        const bool had = c->h_sk_counters && c->h_sk_counters[KMC_CTR_KMERS] != 0;
         rc = settle_sk_polled(c);
         if (rc) return rc;
         if (had) {  // the table changed under the speculative finalize: once more

@@ -297,7 +297,7 @@ void kmc_small_finalize_kernel(GTable g, const u64* __restrict__ sk_counters, u3
     const u64 n = g.counters[KMC_CTR_OCCUPIED];
     const bool ok = n > 0 && n <= KMC_OCC_LIST_CAP && n <= g.occ_list_cap && n <= (u64)gridDim.x * KMC_FIN_CHUNK &&
                     g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0 &&
-                    sk_counters[KMC_CTR_OCCUPIED] == 0 && sk_counters[KMC_CTR_SPILL] == 0;
+                    sk_counters[KMC_CTR_KMERS] == 0;   // (no counts pending in the (k+16)-mer table; its keys stay across launches)
     // (every workgroup that takes part reads these counters before it draws its ticket, and they change only
     // behind the last ticket: all of them decide alike.  A workgroup past the table that starts that late may
     // read zeros -- it leaves either way.)

@@ -83,6 +83,7 @@ struct WalkLds {
     u32 nedges, nnodes;
     u32 qnext;  // next unclaimed tile of this workgroup (waves draw their tiles from it)
     u32 logn;   // records this workgroup has put into its span of the (k+16)-mer log (SkLog)
+    u32 nsk;    // adds this workgroup has made to the (k+16)-mer table
 };
 
 // workspace (device): [WalkWs header | gcnt[NCAP+ECAP] dense snapshot counters | u32 deferred read
@@ -293,6 +294,7 @@ __device__ __forceinline__ void sk_add(WalkLds<KW>& L, const GTable& sk, const S
             return;
         }
     }
+    atomicAdd(&L.nsk, 1u);   // (counts are pending in the table: kmc_sk_unfold_kernel has work)
     if (sk.key_mid) gtable_add<3>(sk, ctx.hi >> 32, lo, 1, mid);
     else gtable_add<2>(sk, mid, lo, 1);
 }
@@ -305,7 +307,7 @@ void kmc_sk_unfold_kernel(GTable sk, int k, GTable g) {
     // work is proportional to the (k+16)-mers the input really has -- none at all for the benchmark input
     const u64 n_occ = min(sk.counters[KMC_CTR_OCCUPIED], sk.occ_list_cap);
     const u64 n_spill = min(sk.counters[KMC_CTR_SPILL], sk.spill_cap);
-    if (n_occ == 0 && n_spill == 0) return;
+    if ((n_occ == 0 && n_spill == 0) || sk.counters[KMC_CTR_KMERS] == 0) return;   // (no entries, or keys without pending counts)
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
@@ -342,7 +344,7 @@ void kmc_sk_unfold_kernel(GTable sk, int k, GTable g) {
 }
 // (the spill counter is cleared by a second, tiny launch: every workgroup of the unfold reads it)
 __global__ void kmc_sk_spill_reset_kernel(GTable sk) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) sk.counters[KMC_CTR_SPILL] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sk.counters[KMC_CTR_SPILL] = 0; sk.counters[KMC_CTR_KMERS] = 0; }   // (KMERS: adds pending, see kmc_walk_kernel)
 }
 
 // Slow path of one step from node offset `s` (s == 0: direct mode).  Returns the next state.
@@ -493,7 +495,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         L.node[i].cnt[0] = 0;
         L.node[i].cnt[1] = 0;
     }
-    if (tid == 0) { L.nedges = warm ? memo->nedges : 0; L.nnodes = warm ? memo->nnodes : 1; L.qnext = KMC_WALK_WAVES; L.logn = 0; }
+    if (tid == 0) { L.nedges = warm ? memo->nedges : 0; L.nnodes = warm ? memo->nnodes : 1; L.qnext = KMC_WALK_WAVES; L.logn = 0; L.nsk = 0; }
     __syncthreads();
     const WCtx root_key = node_encode<KW>(WCtx{0, 0}, 0, k, mask_hi, mask_lo);  // prefix node of depth 0
     u32 root_id = (u32)(kmc_hash_key<KW>(root_key.hi, root_key.lo) >> (64 - KMC_WALK_NLOG));
@@ -762,6 +764,8 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     // flush used to be 8 % of the whole kernel).
     __syncthreads();
     if (tid == 0 && lg.count) lg.count[blockIdx.x] = min(L.logn, lg.cap_wg);   // (every wave has finished its tiles)
+    // adds to the (k+16)-mer table since its last unfold: what tells "keys only" (they stay across launches) from "counts pending"
+    if (tid == 0 && L.nsk) atomicAdd((unsigned long long*)&sk.counters[KMC_CTR_KMERS], (unsigned long long)L.nsk);
     unsigned short* flist = reinterpret_cast<unsigned short*>(L.stage[0]);  // up to NCAP + ECAP entry indices
     u32* fcount = &L.badbits[0][0];
     if (tid == 0) *fcount = 0;
