@@ -662,6 +662,16 @@ int launch_begin(kmc_ctx* c) {
     HIPCHK(c, hipEventRecord(e, c->stream));
     return KMC_OK;
 }
+// an event pair for a launch that records its own timestamps (hipExtLaunchKernelGGL): joins the batch's list unrecorded
+int launch_events(kmc_ctx* c, hipEvent_t* e0, hipEvent_t* e1) {
+    if (c->tb.empty()) c->tb.emplace_back();
+    if (c->tb.back().ev.size() & 1) { c->ev_free.push_back(c->tb.back().ev.back()); c->tb.back().ev.pop_back(); }
+    { int rc = take_event(c, e0); if (rc) return rc; }
+    { int rc = take_event(c, e1); if (rc) { c->ev_free.push_back(*e0); return rc; } }
+    c->tb.back().ev.push_back(*e0);
+    c->tb.back().ev.push_back(*e1);
+    return KMC_OK;
+}
 int launch_end(kmc_ctx* c) {
     hipEvent_t e;
     { int rc = take_event(c, &e); if (rc) return rc; }
@@ -1405,13 +1415,13 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                     if (rc) return fail(c, rc, "walk workspace reset failed");
                 }
                 c->walk_ws_clean = false;
-                rc = launch_begin(c);  // the event pair brackets the walk kernel alone
+                hipEvent_t we0 = nullptr, we1 = nullptr;   // the walk kernel's own start / stop timestamps (no event packets in the stream)
+                rc = launch_events(c, &we0, &we1);
                 if (rc) return rc;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
-                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), skt, lg, 0);
+                                     done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), skt, lg, 0, we0, we1);
                 if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
-                rc = launch_end(c);
-                if (rc) return rc;
+                c->batch_pending = true;
                 if (skt.key_lo) c->sk_dirty = true;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
                                      done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), skt, lg, 1);
@@ -1923,7 +1933,8 @@ static int kmc_finalize_async_impl(kmc_ctx* c) {
     rc = ensure(c, c->o_cnt, fb); if (rc) return rc;
     if (c->KW == 2) { rc = ensure(c, c->o_hi, fb); if (rc) return rc; }
     if (c->sk_dirty) { rc = flush_sk(c); if (rc) return rc; }
-    rc = launch_small_finalize(c, small_finalize_grid(c));
+    // (no second try here as in kmc_finalize: room for 8192 keys at least, whatever the last table looked like)
+    rc = launch_small_finalize(c, std::max(small_finalize_grid(c), 8192 / KMC_FIN_CHUNK));
     if (rc) return rc;
     c->async_fin = true;
     c->sorted_valid = false;   // (until somebody has looked)

@@ -35,6 +35,7 @@
 #pragma once
 #include "../../include/kmc.h"
 #include "kmc_device.hip.h"
+#include <hip/hip_ext.h>
 
 #define KMC_WALK_MAX_K 63
 #define KMC_WALK_MAX_READ 416
@@ -867,7 +868,10 @@ __device__ __forceinline__ void walk_scalar_part(const uint8_t* __restrict__ bas
     __shared__ u64 s_n;
     if (threadIdx.x == 0) {
         s_n = __hip_atomic_load(&ws->n_deferred, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence();  // (the read above before the ticket below)
+        // the read above has RETURNED before the ticket below is drawn (the last ticket clears the counter); waiting for
+        // the load is all that takes -- a __threadfence() here wrote back and invalidated caches in every one of 256
+        // workgroups of a kernel that runs 11 us
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const u32 t = atomicAdd(&ws->scalar_done, 1u);
         if (t == n_blocks - 1) { ws->n_deferred = 0; ws->scalar_done = 0; }
     }
@@ -962,14 +966,21 @@ static inline size_t kmc_walk_workspace_bytes(u64 n_reads) { return KMC_WALK_WS_
 
 template <int KW, bool CANON>
 static inline void kmc_walk_launch_t(hipStream_t st, int grid, int n_cu, const uint8_t* d_bases, const u64* d_vstart, const u64* d_vend,
-                                     u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, u64* gcnt, void* memo, int parity, GTable g, GTable sk, SkLog lg, int phase) {
+                                     u64 n_reads, u64 n_bases, int k, u64 tile_begin, u64 tile_end, WalkWs* hdr, u32* list, u64* gcnt, void* memo, int parity, GTable g, GTable sk, SkLog lg, int phase,
+                                     hipEvent_t e0, hipEvent_t e1) {
     const size_t smem = sizeof(WalkLds<KW>);
     static std::atomic<unsigned long long> attr{0};  // one flag per instantiation and device
     if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_walk_kernel<KW, CANON>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     WalkMemoSlot<KW>* slots = (WalkMemoSlot<KW>*)memo;
     if (phase == 0) {
-        hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_vstart, d_vend, n_reads, k, tile_begin, tile_end, hdr, list,
-                           (const WalkMemoSlot<KW>*)&slots[parity], &slots[parity ^ 1], gcnt, g, sk, lg);
+        // the launch's own start / stop timestamps go to e0 / e1 (hipExtLaunchKernelGGL): what hipEventRecord in front of and
+        // behind the launch measured too, without two more packets in the stream per step
+        if (e0 && e1)
+            hipExtLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), (uint32_t)smem, st, e0, e1, 0u, d_bases, n_bases, d_vstart, d_vend, n_reads, k, tile_begin, tile_end, hdr, list,
+                                  (const WalkMemoSlot<KW>*)&slots[parity], &slots[parity ^ 1], gcnt, g, sk, lg);
+        else
+            hipLaunchKernelGGL((kmc_walk_kernel<KW, CANON>), dim3(grid), dim3(KMC_WALK_THREADS), smem, st, d_bases, n_bases, d_vstart, d_vend, n_reads, k, tile_begin, tile_end, hdr, list,
+                               (const WalkMemoSlot<KW>*)&slots[parity], &slots[parity ^ 1], gcnt, g, sk, lg);
     } else {
         static_assert(((KMC_WALK_NCAP + KMC_WALK_ECAP) * KMC_WALK_STRIDE) % 256 == 0 && 256 % KMC_WALK_STRIDE == 0, "unfold grid must cover the items exactly");
         hipLaunchKernelGGL((kmc_walk_tail_kernel<KW, CANON>), dim3(KMC_WALK_UNFOLD_BLOCKS + n_cu), dim3(256), 0, st,
@@ -1005,7 +1016,8 @@ static inline int kmc_walk_grid(u64 n_tiles, int n_cu) {
     return grid < 1 ? 1 : grid;
 }
 static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool canon, const uint8_t* d_bases,
-                                  const u64* d_vstart, const u64* d_vend, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, int parity, GTable g, GTable sk, SkLog lg, int phase) {
+                                  const u64* d_vstart, const u64* d_vend, u64 n_reads, u64 n_bases, u64 tile_begin, u64 tile_end, void* ws, void* memo, int parity, GTable g, GTable sk, SkLog lg, int phase,
+                                  hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr) {
     if (n_reads >= (1ull << 32) || tile_end <= tile_begin) return KMC_ERR_ARG;
     WalkWs* hdr = (WalkWs*)ws;
     u32* list = (u32*)((char*)ws + KMC_WALK_WS_PREFIX);
@@ -1013,11 +1025,11 @@ static inline int kmc_walk_launch(hipStream_t st, int n_cu, int KW, int k, bool 
     const u64 n_tiles = tile_end - tile_begin;
     const int grid = kmc_walk_grid(n_tiles, n_cu);
     if (KW == 1) {
-        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase);
-        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase);
+        if (canon) kmc_walk_launch_t<1, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase, e0, e1);
+        else kmc_walk_launch_t<1, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase, e0, e1);
     } else {
-        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase);
-        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase);
+        if (canon) kmc_walk_launch_t<2, true>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase, e0, e1);
+        else kmc_walk_launch_t<2, false>(st, grid, n_cu, d_bases, d_vstart, d_vend, n_reads, n_bases, k, tile_begin, tile_end, hdr, list, gcnt_ws, memo, parity, g, sk, lg, phase, e0, e1);
     }
     return hipGetLastError() == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
