@@ -63,6 +63,7 @@ struct kmc_ctx {
     u64* d_counters = nullptr;      // KMC_CTR_N u64
     u64* h_counters = nullptr;      // pinned mirror
     u64* occ_list = nullptr;        // first KMC_OCC_LIST_CAP claimed slots (fast finalize of small tables)
+    u64 *occ_key_lo = nullptr, *occ_key_hi = nullptr;   // ... and their keys, dense (GTable::occ_key_*)
     u32* fin_rank = nullptr;        // ticket counter of kmc_small_finalize_kernel (zero between launches)
     u64* d_mirror = nullptr;        // h_counters as the device sees it (the finalize kernel publishes the counters there)
     u64* h_restore = nullptr;       // pinned: the counters to put back when a drained table is filled again (undrain)
@@ -303,6 +304,8 @@ GTable gtable_of(const kmc_ctx* c, const Table& t) {
     g.spill_cap = c->spill_cap;
     g.occ_list = c->occ_list;
     g.occ_list_cap = c->occ_list ? KMC_OCC_LIST_CAP : 0;
+    g.occ_key_lo = c->occ_key_lo;
+    g.occ_key_hi = c->occ_key_hi;
     return g;
 }
 
@@ -979,10 +982,12 @@ bool arm_risky(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_r
         r.mode = 1;
     } else if (c->tab.cap <= (16ull << 20)) {
         const size_t nb = (size_t)c->tab.cap * sizeof(u64);
-        if (ensure(c, c->snap_lo, nb) || ensure(c, c->snap_cnt, nb) || (c->KW == 2 && ensure(c, c->snap_hi, nb)) || ensure(c, c->snap_occ, (size_t)KMC_OCC_LIST_CAP * sizeof(u64))) return false;
+        if (ensure(c, c->snap_lo, nb) || ensure(c, c->snap_cnt, nb) || (c->KW == 2 && ensure(c, c->snap_hi, nb)) || ensure(c, c->snap_occ, 3 * (size_t)KMC_OCC_LIST_CAP * sizeof(u64))) return false;
         bool ok = hipMemcpyAsync(c->snap_lo.p, c->tab.lo, nb, hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
                   hipMemcpyAsync(c->snap_cnt.p, c->tab.cnt, nb, hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
-                  hipMemcpyAsync(c->snap_occ.p, c->occ_list, (size_t)KMC_OCC_LIST_CAP * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+                  hipMemcpyAsync(c->snap_occ.p, c->occ_list, (size_t)KMC_OCC_LIST_CAP * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
+                  hipMemcpyAsync((u64*)c->snap_occ.p + KMC_OCC_LIST_CAP, c->occ_key_lo, (size_t)KMC_OCC_LIST_CAP * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) == hipSuccess &&
+                  hipMemcpyAsync((u64*)c->snap_occ.p + 2 * (size_t)KMC_OCC_LIST_CAP, c->occ_key_hi, (size_t)KMC_OCC_LIST_CAP * sizeof(u64), hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
         if (ok && c->KW == 2) ok = hipMemcpyAsync(c->snap_hi.p, c->tab.hi, nb, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
         if (!ok) { (void)hipGetLastError(); return false; }
         r.mode = 2;
@@ -1031,6 +1036,8 @@ int recover_overflow(kmc_ctx* c) {
         HIPCHK(c, hipMemcpyAsync(c->tab.cnt, c->snap_cnt.p, nb, hipMemcpyDeviceToDevice, c->stream));
         if (c->KW == 2) HIPCHK(c, hipMemcpyAsync(c->tab.hi, c->snap_hi.p, nb, hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->occ_list, c->snap_occ.p, (size_t)KMC_OCC_LIST_CAP * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->occ_key_lo, (u64*)c->snap_occ.p + KMC_OCC_LIST_CAP, (size_t)KMC_OCC_LIST_CAP * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->occ_key_hi, (u64*)c->snap_occ.p + 2 * (size_t)KMC_OCC_LIST_CAP, (size_t)KMC_OCC_LIST_CAP * sizeof(u64), hipMemcpyDeviceToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, c->stream));
     }
     { int rs = sk_clear(c); if (rs) return rs; }  // (its counts belong to the launch that is being undone)
@@ -1201,7 +1208,9 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     }
     c->st.algo_last = algo;
 
-    harvest_timing(c);       // (batches that have finished since; never waits)
+    // (the events of finished batches are read in kmc_get_stats / kmc_poll -- or here and in kmc_finalize once a few
+    //  have piled up: reading them costs microseconds of host time between a step's synchronisation and the next launch)
+    if (c->tb.size() >= 4) harvest_timing(c);
     c->tb.emplace_back();    // this batch's launch events
     c->tb.back().n_bases = n_bases;
     int rc = KMC_OK;
@@ -1585,6 +1594,8 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
     if (c->h_counters) (void)hipHostFree(c->h_counters);
     if (c->h_restore) (void)hipHostFree(c->h_restore);
     if (c->occ_list) (void)hipFree(c->occ_list);
+    if (c->occ_key_lo) (void)hipFree(c->occ_key_lo);
+    if (c->occ_key_hi) (void)hipFree(c->occ_key_hi);
     if (c->fin_rank) (void)hipFree(c->fin_rank);
     if (c->spill_hi) (void)hipFree(c->spill_hi);
     if (c->spill_lo) (void)hipFree(c->spill_lo);
@@ -1639,6 +1650,8 @@ static int kmc_create_impl(kmc_ctx** out, const kmc_config* cfg) {
         u64 cap = next_pow2(std::max<u64>(cfg->capacity_hint * 2, 1ull << 20));
         c->spill_cap = std::max<u64>(cap / 4, 1ull << 18);
         HIPCHK(c, hipMalloc((void**)&c->occ_list, KMC_OCC_LIST_CAP * sizeof(u64)));
+        HIPCHK(c, hipMalloc((void**)&c->occ_key_lo, KMC_OCC_LIST_CAP * sizeof(u64)));
+        HIPCHK(c, hipMalloc((void**)&c->occ_key_hi, KMC_OCC_LIST_CAP * sizeof(u64)));
         HIPCHK(c, hipMalloc((void**)&c->fin_rank, 16 * sizeof(u32)));
         HIPCHK(c, hipMemsetAsync(c->fin_rank, 0, 16 * sizeof(u32), c->stream));
         HIPCHK(c, hipMalloc((void**)&c->spill_lo, c->spill_cap * sizeof(u64)));
@@ -1784,7 +1797,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     rc = resolve_async(c);   // (a finalize queued by kmc_finalize_async: its view, when it produced one, is the result)
     if (rc) return rc;
     if (c->drained && c->sorted_valid) {  // nothing was added since the last finalize (which emptied the table into the view)
-        harvest_timing(c);
+        if (c->tb.size() >= 4) harvest_timing(c);
         if (n_distinct) *n_distinct = c->n_sorted;
         if (n_total) *n_total = c->st.n_kmers;
         return KMC_OK;
@@ -1914,7 +1927,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     c->sorted_valid = true;
     c->st.n_distinct = n;
     c->st.n_kmers = n ? n_kmers : 0;
-    harvest_timing(c);
+    if (c->tb.size() >= 4) harvest_timing(c);
     if (n_distinct) *n_distinct = n;
     if (n_total) *n_total = c->st.n_kmers;
     return KMC_OK;

@@ -45,6 +45,8 @@ struct GTable {
     u64  spill_cap;
     u64* occ_list;     // slot index of the i-th claimed slot, for i < occ_list_cap (small-table fast finalize)
     u64  occ_list_cap;
+    u64* occ_key_lo;   // the i-th claimed slot's KEY, dense (nullptr: not kept): the small-table finalize reads the keys of a
+    u64* occ_key_hi;   // table with coalesced loads instead of a dependent occ_list -> slot -> key chain per workgroup and tile
 };
 
 // claimed slots listed (small-table finalize, reset through the list, slab packing, cheap table snapshots).  Round 3: 32768 ->
@@ -120,7 +122,7 @@ __device__ __forceinline__ void gtable_add(const GTable& g, u64 hi, u64 lo, u64 
                     cur = atomicCAS((unsigned long long*)&g.key_lo[h], KMC_EMPTY64, lo);
                     if (cur == KMC_EMPTY64) {
                         const u64 i = atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
-                        if (i < g.occ_list_cap) g.occ_list[i] = h;
+                        if (i < g.occ_list_cap) { g.occ_list[i] = h; if (g.occ_key_lo) g.occ_key_lo[i] = lo; }
                         cur = lo;
                     }
                 }
@@ -145,7 +147,7 @@ __device__ __forceinline__ void gtable_add(const GTable& g, u64 hi, u64 lo, u64 
                         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                         __hip_atomic_store(&g.key_hi[h], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         const u64 i = atomicAdd((unsigned long long*)&g.counters[KMC_CTR_OCCUPIED], 1ull);
-                        if (i < g.occ_list_cap) g.occ_list[i] = h;
+                        if (i < g.occ_list_cap) { g.occ_list[i] = h; if (g.occ_key_lo) { g.occ_key_lo[i] = lo; g.occ_key_hi[i] = hi; } }
                         atomicAdd((unsigned long long*)&g.count[h], cnt);
                         done = true;
                     }

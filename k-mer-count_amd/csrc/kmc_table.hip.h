@@ -316,29 +316,40 @@ void kmc_small_finalize_kernel(GTable g, const u64* __restrict__ sk_counters, u3
     const u32 m = tid & (KMC_FIN_CHUNK - 1u), seg = tid / KMC_FIN_CHUNK;
     constexpr u32 NSEG = 1024 / KMC_FIN_CHUNK;
     const u64 mine_i = (u64)blockIdx.x * KMC_FIN_CHUNK + m;
+    // keys come from the dense key list (GTable::occ_key_*: coalesced, no occ_list -> slot -> key chain); counts via the slot
     u64 mlo = ~0ull, mhi = ~0ull, mcnt = 0;
     if (mine_i < n) {
-        const u64 mslot = g.occ_list[mine_i];
-        mlo = g.key_lo[mslot];
-        mhi = KW == 2 ? g.key_hi[mslot] : 0ull;
-        mcnt = g.count[mslot];
+        mlo = g.occ_key_lo[mine_i];
+        mhi = KW == 2 ? g.occ_key_hi[mine_i] : 0ull;
+        mcnt = g.count[g.occ_list[mine_i]];
     }
     if (tid < KMC_FIN_CHUNK) s_rank[tid] = 0;
     u64 sum = 0;  // (workgroup 0 also adds up all counts)
     u32 r = 0;
+    constexpr int KPT = KMC_FIN_TILE / 1024;
+    u64 nlo[KPT], nhi[KPT];   // the next tile, on its way while this one is compared
+    auto load_tile = [&](u64 t0) {
+#pragma unroll
+        for (int e = 0; e < KPT; ++e) {
+            const u64 i = t0 + tid + 1024u * e;
+            nlo[e] = 0; nhi[e] = 0;
+            if (i < n) {
+                nlo[e] = g.occ_key_lo[i];
+                if (KW == 2) nhi[e] = g.occ_key_hi[i];
+                if (blockIdx.x == 0) sum += g.count[g.occ_list[i]];
+            }
+        }
+    };
+    load_tile(0);
     for (u64 t0 = 0; t0 < n; t0 += KMC_FIN_TILE) {
         const u32 tn = (u32)min((u64)KMC_FIN_TILE, n - t0);
         __syncthreads();  // (the previous tile has been read)
 #pragma unroll
-        for (int e = 0; e < KMC_FIN_TILE / 1024; ++e) {
+        for (int e = 0; e < KPT; ++e) {
             const u32 j = tid + 1024u * e;
-            if (j < tn) {
-                const u64 slot = g.occ_list[t0 + j];
-                t_lo[j] = g.key_lo[slot];
-                if (KW == 2) t_hi[j] = g.key_hi[slot];
-                if (blockIdx.x == 0) sum += g.count[slot];
-            }
+            if (j < tn) { t_lo[j] = nlo[e]; if (KW == 2) t_hi[j] = nhi[e]; }
         }
+        if (t0 + KMC_FIN_TILE < n) load_tile(t0 + KMC_FIN_TILE);   // (block-uniform)
         __syncthreads();
         // elements seg, seg + 64, ... of the tile against my key (one address per quarter wave: LDS broadcast reads);
         // four independent reads per trip, so that the loop does not pay an LDS round trip per element
