@@ -392,9 +392,9 @@ def main():
 
 
 # The sort pipeline's modelled HBM traffic per k-mer, in key units (8 B for k <= 31, 16 B above), DESIGN.md 4.3.
-SORT_MODEL_KEY_UNITS = 13
-SORT_MODEL_TEXT = ("extraction writes one key per base position; per level: histogram read + scatter read + write; leaves: read, staged keys + "
-                   "counts written; gather: both read, both written")
+SORT_MODEL_KEY_UNITS = 8
+SORT_MODEL_TEXT = ("extraction writes one key per base position (its level-0 histogram is built on the way); level 0: scatter read + write; "
+                   "level 1: histogram read + scatter read + write; leaves: read, (key, count) pairs written in place")
 
 
 if __name__ == "__main__":

@@ -173,9 +173,12 @@ int kmc_export(kmc_ctx* ctx, uint64_t* key_hi, uint64_t* key_lo, uint64_t* count
 
 /* Device pointers to the sorted table of the last kmc_finalize (owned by the ctx, valid until the
  * next finalize/reset/destroy).  d_key_hi is NULL when keys fit one word.
- * Ordering contract: when kmc_finalize returns, every kernel that writes the view has FINISHED (finalize
- * synchronises the ctx stream on each of its paths), so the arrays may be read from any stream, by a peer
- * copy or by a collective without further synchronisation. */
+ * Ordering contract: when kmc_finalize returns, every entry of the view has been written and released to device
+ * memory, so the arrays may be read from any stream, by a peer copy or by a collective without further
+ * synchronisation.  (The large-table paths synchronise the ctx stream.  The small-table kernel tells the host itself:
+ * each workgroup releases its entries before it draws its ticket, and the last ticket's workgroup writes the word
+ * kmc_finalize waits on to pinned host memory -- the kernel may still be clearing table slots at that moment, which
+ * only the ctx stream's later work cares about.) */
 int kmc_export_device(kmc_ctx* ctx, const void** d_key_hi, const void** d_key_lo,
                       const void** d_count, uint64_t* n_distinct);
 

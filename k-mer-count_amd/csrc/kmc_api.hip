@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <atomic>
 #include <climits>
+#include <chrono>
 #include <deque>
 #include <thread>
 #include <new>
@@ -424,8 +425,25 @@ int poll(kmc_ctx* c) {
 }
 // The poll right behind a speculative kmc_small_finalize_kernel: when the kernel succeeded it has PUBLISHED the
 // counters to h_counters itself (and emptied the table): no read-back copy, one synchronisation.
+// The kernel writes mirror[FINSEQ] = its number LAST, whatever it decided: the host waits for that word in the pinned
+// mirror rather than for the end of the kernel (the end-of-kernel release + the completion signal cost microseconds of a
+// 1.4 ms step, and what the kernel still does after the word -- clearing slots -- is device work in stream order).
+// A kernel that never publishes (a fault) is found by the synchronisation this falls back to.
 int poll_fin(kmc_ctx* c) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        const volatile u64* seqw = (const volatile u64*)&c->h_counters[KMC_CTR_FINSEQ];
+        static const bool no_spin = getenv("KMC_NO_MIRROR_SPIN") != nullptr;
+        bool seen = false;
+        if (!no_spin) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (u32 it = 1; !(seen = (*seqw == c->fin_seq)); ++it) {
+                __builtin_ia32_pause();
+                if ((it & 0xfffu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        }
+        if (!seen) HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     c->st.n_async_ok = c->h_counters[KMC_CTR_FINOK];
     c->st.n_async_slabs_skipped = c->h_counters[KMC_CTR_FINSKIP];
     if (c->h_counters[KMC_CTR_FASTFIN] != 1 || c->h_counters[KMC_CTR_FINSEQ] != c->fin_seq) {   // it gave up: read the counters the usual way
@@ -1425,11 +1443,13 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 }
                 c->walk_ws_clean = false;
                 hipEvent_t we0 = nullptr, we1 = nullptr;   // the walk kernel's own start / stop timestamps (no event packets in the stream)
-                rc = launch_events(c, &we0, &we1);
+                static const bool ev_records = getenv("KMC_WALK_EVENT_RECORDS") != nullptr;   // (A/B switch: hipEventRecord around the launch instead)
+                if (ev_records) rc = launch_begin(c); else rc = launch_events(c, &we0, &we1);
                 if (rc) return rc;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
                                      done, done + take, c->walk_ws.p, c->walk_memo.p, c->memo_parity, gtable_of(c, c->tab), skt, lg, 0, we0, we1);
                 if (rc) return fail(c, rc, "walk kernel launch failed: %s", hipGetErrorString(hipGetLastError()));
+                if (ev_records) { rc = launch_end(c); if (rc) return rc; }
                 c->batch_pending = true;
                 if (skt.key_lo) c->sk_dirty = true;
                 rc = kmc_walk_launch(c->stream, c->n_cu, c->KW, c->cfg.k, c->cfg.canonical != 0, d_bases, d_vs, d_ve, n_v, n_bases,
@@ -2485,6 +2505,11 @@ extern "C" int kmc_debug_leaf_stamps(uint64_t* out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(kmc_leaf_stamps), 16 * sizeof(uint64_t)) != hipSuccess) return KMC_ERR_HIP;
     if (reset) { uint64_t z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(kmc_leaf_stamps), z, sizeof(z)) != hipSuccess) return KMC_ERR_HIP; }
     return KMC_OK;
+}
+#endif
+#ifdef KMC_WALK_STAMPS
+extern "C" int kmc_debug_walk_stamps(uint64_t* out, uint32_t n_words) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(kmc_walk_stamps), std::min<size_t>(n_words, 256 * 24) * sizeof(uint64_t)) == hipSuccess ? KMC_OK : KMC_ERR_HIP;
 }
 #endif
 // ---- the ABI proper: no C++ exception leaves the library (kmc.h: "no exception or abort crosses the ABI") ----

@@ -279,7 +279,8 @@ __global__ void kmc_merge_slabs_kernel(GTable g, const u64* __restrict__ slabs, 
 #define KMC_FIN_CHUNK 16
 // host_mirror: the ctx's pinned mirror of [count-table counters | (k+16)-mer-table counters].  The host clears
 // mirror[KMC_CTR_FASTFIN] before the launch; 1 afterwards means: sorted view written, counters published
-// (mirror[KMC_CTR_SUM2] = sum of all counts), table drained.  The device copies of FASTFIN / SUM2 are never written.
+// (mirror[KMC_CTR_SUM2] = sum of all counts), table drained; mirror[KMC_CTR_FINSEQ] = seq is written LAST (the host waits on it).
+// The device copy of FASTFIN is never written; the device copy of SUM2 carries the sum from workgroup 0 to the publisher.
 // ticket[0]: the ticket counter; ticket[1], ticket[2]: launches that produced a view / oversize slabs they saw, since
 // kmc_create (a caller that queues several finalizes without waiting -- kmc_finalize_async -- checks afterwards that
 // every one of them delivered); seq: this launch's number, published with everything else.
@@ -304,9 +305,10 @@ void kmc_small_finalize_kernel(GTable g, const u64* __restrict__ sk_counters, u3
     if (!ok) {
         if (blockIdx.x == 0 && tid == 0) {   // "gave up": the table is as it was
             __hip_atomic_store(&host_mirror[KMC_CTR_FASTFIN], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&host_mirror[KMC_CTR_FINSEQ], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_mirror[KMC_CTR_FINOK], (u64)ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(&host_mirror[KMC_CTR_FINSKIP], (u64)ticket[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __threadfence_system();   // (FINSEQ is the word the host waits on: last)
+            __hip_atomic_store(&host_mirror[KMC_CTR_FINSEQ], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return;
     }
@@ -370,42 +372,54 @@ void kmc_small_finalize_kernel(GTable g, const u64* __restrict__ sk_counters, u3
     r += __shfl_xor(r, 16);   // the four segments of a wave
     r += __shfl_xor(r, 32);
     if ((tid & 63u) < KMC_FIN_CHUNK && r) atomicAdd(&s_rank[m], r);
-    // every read of the table by this workgroup has COMPLETED before its ticket is drawn (the last workgroup
-    // empties the table behind the last ticket)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) s_last = (atomicAdd(ticket, 1u) == nb - 1) ? 1u : 0u;
-    if (tid < KMC_FIN_CHUNK && mine_i < n) {
-        const u32 pos = s_rank[tid];
-        out_lo[pos] = mlo;
-        if (KW == 2) out_hi[pos] = mhi;
-        out_cnt[pos] = mcnt;
-    }
     if (blockIdx.x == 0) {
         sum = wave_sum_u64(sum);
         if ((tid & 63) == 0) s_sum[tid >> 6] = sum;
     }
+    // every read of the table by this workgroup has COMPLETED before its ticket is drawn (the last workgroup
+    // empties the table behind the last ticket)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (blockIdx.x == 0 && tid == 0) {
-        u64 tot = 0;
-        for (int w = 0; w < 16; ++w) tot += s_sum[w];
-        __hip_atomic_store(&host_mirror[KMC_CTR_SUM2], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(&host_mirror[KMC_CTR_FASTFIN], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (tid < 64) {   // wave 0: the workgroup's 16 entries of the view, then its ticket
+        if (tid < KMC_FIN_CHUNK && mine_i < n) {
+            const u32 pos = s_rank[tid];
+            out_lo[pos] = mlo;
+            if (KW == 2) out_hi[pos] = mhi;
+            out_cnt[pos] = mcnt;
+        }
+        if (tid == 0 && blockIdx.x == 0) {   // the sum of all counts, for the workgroup that publishes (device word SUM2: otherwise unused)
+            u64 tot = 0;
+            for (int w = 0; w < 16; ++w) tot += s_sum[w];
+            __hip_atomic_store(&g.counters[KMC_CTR_SUM2], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // (release: the entries above are in memory before the ticket says so -- the host is told "view complete" by the
+        // last ticket's workgroup, possibly before this kernel has ended, and may hand the view to any stream then)
+        __threadfence();
+        if (tid == 0) s_last = (atomicAdd(ticket, 1u) == nb - 1) ? 1u : 0u;
     }
+    __syncthreads();
     if (!s_last) return;
     // ---- the last workgroup: publish the counters, empty the table (every workgroup has finished READING it) ----
+    // The host waits on mirror[FINSEQ] (kmc_api.hip: poll_fin), not on the end of the kernel: that word is written
+    // last, behind a system-scope fence; everything after it touches device memory only, in stream order before
+    // whatever the host launches next.
     if (tid < KMC_CTR_FINSEQ && tid != KMC_CTR_SUM2 && tid != KMC_CTR_FASTFIN)
         __hip_atomic_store(&host_mirror[tid], g.counters[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     else if (tid == KMC_CTR_FINSEQ) {
         const u32 okn = ticket[1] + 1u, skn = ticket[2] + (u32)g.counters[KMC_CTR_SLABSKIP];
         ticket[1] = okn;
         ticket[2] = skn;
-        __hip_atomic_store(&host_mirror[KMC_CTR_FINSEQ], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&host_mirror[KMC_CTR_FINOK], (u64)okn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         __hip_atomic_store(&host_mirror[KMC_CTR_FINSKIP], (u64)skn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const u64 tot = __hip_atomic_load(&g.counters[KMC_CTR_SUM2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&host_mirror[KMC_CTR_SUM2], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_mirror[KMC_CTR_FASTFIN], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     else if (tid >= 64 && tid < 64 + KMC_CTR_N)
         __hip_atomic_store(&host_mirror[KMC_CTR_N + tid - 64], sk_counters[tid - 64], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&host_mirror[KMC_CTR_FINSEQ], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     for (u64 i = tid; i < n; i += 1024) {
         const u64 slot = g.occ_list[i];
         if (KW == 2) { g.key_hi[slot] = KMC_EMPTY64; g.key_lo[slot] = 0; } else g.key_lo[slot] = KMC_EMPTY64;

@@ -474,6 +474,15 @@ __device__ __forceinline__ u32 walk_encode16(uint4 v, u32& x0, u32& x1, u32& x2,
     return u;
 }
 
+// Diagnostic build only (tools/build_variant.sh stamps "-DKMC_WALK_STAMPS", tools/walk_stamps.py): the 100 MHz wall clock at
+// the kernel's milestones, per workgroup: [0] entry, [1] LDS initialised, [2 + w] wave w left its tile loop, [18] all
+// waves there, [19] dense flush done, [20] end, [21] wave 0 has stepped its first tile.
+#ifdef KMC_WALK_STAMPS
+__device__ unsigned long long kmc_walk_stamps[256 * 24];
+#define WALK_STAMP(i) do { kmc_walk_stamps[(blockIdx.x & 255u) * 24 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define WALK_STAMP(i) do { } while (0)
+#endif
 template <int KW, bool CANON>
 __global__ __launch_bounds__(KMC_WALK_THREADS)
 void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* __restrict__ vstart, const u64* __restrict__ vend, u64 n_reads,
@@ -487,6 +496,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
 
+    if (tid == 0) WALK_STAMP(0);
     const bool warm = memo && memo->tag == (KMC_WALK_MEMO_TAG | (u64)k);  // workgroup-uniform
     for (int i = tid; i < KMC_WALK_ECAP; i += KMC_WALK_THREADS) { L.edge[i].kv = warm ? memo->ekv[i] : ~0ull; L.edge[i].cnt[0] = 0; L.edge[i].cnt[1] = 0; }
     for (int i = tid; i < KMC_WALK_NCAP; i += KMC_WALK_THREADS) {
@@ -504,6 +514,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     if (tid == 0 && !warm) { L.nkeys[root_id] = root_key.lo; if (KW == 2) L.nkeys_hi[root_id] = root_key.hi; }
     __syncthreads();
     const u32 s_root = root_id << 4;
+    if (tid == 0) WALK_STAMP(1);
 
     u32* stage = L.stage[wv];
     u64 nk = 0, ndirect = 0;
@@ -737,6 +748,9 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         consume(x, cur, rbase, np_u);
         if (last) {
             step_phase(cur, tile);
+#ifdef KMC_WALK_STAMPS
+            if (wv == 0 && lane == 0 && tile == gw) WALK_STAMP(21);
+#endif
             cur = nxt;
             tile = nxt_tile;
             rbase = 0;
@@ -750,6 +764,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         if (!live) break;
         half(vb, va);
     }
+    if (lane == 0) WALK_STAMP(2 + wv);
     nk = wave_sum_u64(nk);
     ndirect = wave_sum_u64(ndirect);
     if (lane == 0) {
@@ -764,6 +779,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     // dependent ones on the few threads that happened to own a used entry (measured: 140 us -> the
     // flush used to be 8 % of the whole kernel).
     __syncthreads();
+    if (tid == 0) WALK_STAMP(18);
     if (tid == 0 && lg.count) lg.count[blockIdx.x] = min(L.logn, lg.cap_wg);   // (every wave has finished its tiles)
     // adds to the (k+16)-mer table since its last unfold: what tells "keys only" (they stay across launches) from "counts pending"
     if (tid == 0 && L.nsk) atomicAdd((unsigned long long*)&sk.counters[KMC_CTR_KMERS], (unsigned long long)L.nsk);
@@ -787,6 +803,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         }
     }
     __syncthreads();
+    if (tid == 0) WALK_STAMP(19);
     const u32 n_items = *fcount * KMC_WALK_STRIDE;
     // every workgroup holds nearly the same entries in nearly the same order (slot = hash of the
     // key): start each one at a different place so that they do not all hit one address at a time
@@ -821,6 +838,7 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
         }
         if (tid == 0) { memo_out->nedges = L.nedges; memo_out->nnodes = L.nnodes; memo_out->tag = KMC_WALK_MEMO_TAG | (u64)k; }
     }
+    if (tid == 0) WALK_STAMP(20);
 }
 
 // Turns the traversal counters that all workgroups reduced into gcnt (one per snapshot slot) into
