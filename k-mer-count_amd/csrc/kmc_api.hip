@@ -106,7 +106,7 @@ struct kmc_ctx {
     u64 acc_hint = 0;        // positions the caller expects in all (kmc_count_file: the file size); sizes the first allocation
     DevBuf lr_rank;  // LR mode: rank of every position's 27-mer among the batch's distinct 27-mers
     // hand-written MSD radix sort (kmc_msd.hip.h): per-range histograms, segment lists, terminals
-    DevBuf m_hist, m_stot, m_bsum, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_w[2];
+    DevBuf m_hist, m_stot, m_bsum, m_rmin, m_rmax, m_seg[2], m_first, m_cbase, m_skip, m_term, m_ord, m_bitmap, m_rank, m_nd, m_base, m_ctl, m_clist, m_w[2];
     MsdCtl* h_ctl = nullptr;  // pinned mirror of the sort's device counters
     struct Run { u64 *hi = nullptr, *lo = nullptr, *cnt = nullptr; u64 n = 0, cap = 0; u64 total = 0; bool total_known = false; };
     std::vector<Run> runs;       // live runs
@@ -769,7 +769,9 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     if (KW == 2 && !w[0] && c->msd_dup_heavy) leaf_cap = 1024;
     const bool clustered = repeated_keys || c->msd_dup_heavy;   // (one-word leaves: the larger wave scratch)
     const u64 max_seg = n / leaf_cap + 257;
-    const u64 max_ranges = n / KMC_MSD_RANGE + max_seg + 1;
+    const u32 cnt_bits = weights ? 0u : (u32)KMC_MSD_CNT_BITS;   // long spans with few bits left: LDS histograms (plain counts only)
+    const u32 rsz = pre0 ? (u32)KMC_MSD_RANGE : msd_range_for(n);   // keys per range (a workgroup of the histogram / scatter passes)
+    const u64 max_ranges = n / rsz + max_seg + 1;
     const u64 term_cap = 16 * (n / leaf_cap) + 65536;
     const u64 n_words = (n + 63) / 64;
     int rc;
@@ -788,6 +790,7 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     MSD_ENSURE(c->m_bitmap, n_words * sizeof(u64));
     MSD_ENSURE(c->m_rank, n_words * sizeof(u32));
     MSD_ENSURE(c->m_nd, term_cap * sizeof(u32));
+    MSD_ENSURE(c->m_clist, max_seg * sizeof(u32));   // (kind-2 terminals hold more than leaf_cap keys each)
     MSD_ENSURE(c->m_base, term_cap * sizeof(u32));
     MSD_ENSURE(c->m_ctl, sizeof(MsdCtl));
     MSD_ENSURE(c->m_bsum, (std::max<u64>(n_words, term_cap) / KMC_SCAN_PER_BLOCK + 2) * sizeof(u32));
@@ -805,31 +808,31 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
         MsdSeg* seg = (MsdSeg*)c->m_seg[cur].p;
         MsdSeg* next = (MsdSeg*)c->m_seg[cur ^ 1].p;
         u32* first = (u32*)c->m_first.p;
-        hipLaunchKernelGGL(kmc_msd_ranges_kernel, dim3(1), dim3(1024), 0, c->stream, (const MsdSeg*)seg, n_seg, first, ctl);
-        const u32 grid = (u32)std::min<u64>(n / KMC_MSD_RANGE + n_seg + 1, max_ranges);
+        hipLaunchKernelGGL(kmc_msd_ranges_kernel, dim3(1), dim3(1024), 0, c->stream, (const MsdSeg*)seg, n_seg, rsz, first, ctl);
+        const u32 grid = (u32)std::min<u64>(n / rsz + n_seg + 1, max_ranges);
         const bool have = pre0 && l == 0;   // this level's histogram rows came with the keys
         u32* const hist_l = have ? (u32*)c->a_hist.p : (u32*)c->m_hist.p;
         u64* const rmin_l = have ? (u64*)c->a_rand.p : (u64*)c->m_rmin.p;
         u64* const rmax_l = have ? (u64*)c->a_ror.p : (u64*)c->m_rmax.p;
         if (have) { /* nothing to read back */ }
         else if (KW == 1) hipLaunchKernelGGL(kmc_msd_hist_kernel<1>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1],
-                                        (const MsdSeg*)seg, n_seg, (const u32*)first, (int)kb, l == 0 ? 1 : 0, hist_l, rmin_l, rmax_l, (const MsdCtl*)ctl);
+                                        (const MsdSeg*)seg, n_seg, (const u32*)first, rsz, (int)kb, l == 0 ? 1 : 0, hist_l, rmin_l, rmax_l, (const MsdCtl*)ctl);
         else hipLaunchKernelGGL(kmc_msd_hist_kernel<2>, dim3(grid), dim3(KMC_MSD_THREADS), 0, c->stream, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1],
-                                (const MsdSeg*)seg, n_seg, (const u32*)first, (int)kb, l == 0 ? 1 : 0, hist_l, rmin_l, rmax_l, (const MsdCtl*)ctl);
+                                (const MsdSeg*)seg, n_seg, (const u32*)first, rsz, (int)kb, l == 0 ? 1 : 0, hist_l, rmin_l, rmax_l, (const MsdCtl*)ctl);
         HIPCHK(c, hipMemsetAsync(&ctl->n_next, 0, sizeof(u32), c->stream));
         // few segments = long ones: a wave per digit column (257 workgroups of four waves for a single segment: level 0),
         // 64 workgroups per segment while there are few, one when there are many (short ones)
         const u32 S = n_seg <= 8 ? 257u : (n_seg <= 4096 ? 64u : 1u);
         hipLaunchKernelGGL(kmc_msd_scan_a_kernel, dim3(n_seg * S), dim3(KMC_MSD_THREADS), 0, c->stream, n_seg, S, (const u32*)first, hist_l, (u32*)c->m_stot.p);
         hipLaunchKernelGGL(kmc_msd_scan_kernel, dim3(n_seg), dim3(KMC_MSD_ND), 0, c->stream, (const MsdSeg*)seg, n_seg, (const u32*)first, hist_l, (const u32*)c->m_stot.p,
-                           (const u64*)rmin_l, (const u64*)rmax_l, (u32*)c->m_cbase.p, (u32*)c->m_skip.p, l == 0 ? 1 : 0, leaf_cap,
+                           (const u64*)rmin_l, (const u64*)rmax_l, (u32*)c->m_cbase.p, (u32*)c->m_skip.p, l == 0 ? 1 : 0, n_seg <= 8 ? 1 : 0, leaf_cap, cnt_bits,
                            next, (u32)max_seg, (MsdTerm*)c->m_term.p, (u32)term_cap, (unsigned long long*)c->m_bitmap.p, ctl);
 #define MSD_SCATTER(KWV, WV)                                                                                                              \
         do {                                                                                                                              \
             static std::atomic<unsigned long long> attr{0};                                                                               \
             if (kmc_attr_once(attr)) (void)hipFuncSetAttribute((const void*)kmc_msd_scatter_kernel<KWV, WV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(MsdScatterLds<KWV, WV>)); \
             hipLaunchKernelGGL((kmc_msd_scatter_kernel<KWV, WV>), dim3(grid), dim3(1024), sizeof(MsdScatterLds<KWV, WV>), c->stream, hi[0], lo[0], w[0], hi[1], lo[1], w[1], \
-                               (const MsdSeg*)seg, n_seg, (const u32*)first, (const u32*)hist_l, (const u32*)c->m_cbase.p, (const u32*)c->m_skip.p, \
+                               (const MsdSeg*)seg, n_seg, (const u32*)first, rsz, (const u32*)hist_l, (const u32*)c->m_cbase.p, (const u32*)c->m_skip.p, \
                                (int)kb, l == 0 ? 1 : 0, (const MsdCtl*)ctl);                                                 \
         } while (0)
         if (KW == 1) { if (weights) MSD_SCATTER(1, true); else MSD_SCATTER(1, false); }
@@ -852,7 +855,8 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
         hipLaunchKernelGGL(kmc_scan_final_kernel<1>, dim3(nb), dim3(256), 0, c->stream, (const void*)c->m_bitmap.p, (u32)n_words, (const u32*)c->m_bsum.p, (u32*)c->m_rank.p);
     }
     hipLaunchKernelGGL(kmc_msd_order_kernel, dim3(grid_for(c, n_term, 256)), dim3(256), 0, c->stream, (const MsdTerm*)c->m_term.p, n_term,
-                       (const unsigned long long*)c->m_bitmap.p, (const u32*)c->m_rank.p, (MsdTerm*)c->m_ord.p);
+                       (const unsigned long long*)c->m_bitmap.p, (const u32*)c->m_rank.p, (MsdTerm*)c->m_ord.p, (u32*)c->m_clist.p, ctl);
+    const u32 n_cnt = c->h_ctl->n_cnt;   // (as of the last level's poll: only the levels' scans add to it)
     // the run the leaves write into: at most one pair per valid key
     const u64 run_cap = std::max<u64>(weights ? n : std::min<u64>(n, (u64)c->h_ctl->n_valid), 1);
     kmc_ctx::Run run;
@@ -876,6 +880,13 @@ int msd_sort_to_run(kmc_ctx* c, u64* const hi[2], u64* const lo[2], u64* const w
     else if (leaf_cap > 1024) MSD_LEAF(2, false, KMC_MSD_LEAF2, 16);
     else MSD_LEAF(2, false, 1024, 128);
 #undef MSD_LEAF
+    if (n_cnt) {
+        if (n_cnt > max_seg) { c->run_pool.push_back(run); return fail(c, KMC_ERR_HIP, "msd sort: more counted spans than segments (internal error)"); }
+        if (KW == 1) hipLaunchKernelGGL(kmc_msd_count_kernel<1>, dim3(n_cnt), dim3(1024), 0, c->stream, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1],
+                                        (const MsdTerm*)c->m_ord.p, (const u32*)c->m_clist.p, n_cnt, run.hi, run.lo, run.cnt, (u32*)c->m_nd.p, ctl);
+        else hipLaunchKernelGGL(kmc_msd_count_kernel<2>, dim3(n_cnt), dim3(1024), 0, c->stream, (const u64*)hi[0], (const u64*)lo[0], (const u64*)hi[1], (const u64*)lo[1],
+                                (const MsdTerm*)c->m_ord.p, (const u32*)c->m_clist.p, n_cnt, run.hi, run.lo, run.cnt, (u32*)c->m_nd.p, ctl);
+    }
     auto give_back = [&](int code, const char* what) { c->run_pool.push_back(run); return fail(c, code, "msd sort: %s", what); };
     if (hipGetLastError() != hipSuccess) return give_back(KMC_ERR_HIP, "leaf launch failed");
     if (hipMemcpyAsync(c->h_ctl, ctl, sizeof(MsdCtl), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
@@ -1335,6 +1346,7 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                     kmc_ctx::Run run;
                     rc = msd_sort_to_run(c, khi, klo, kwt, n, 2u * (unsigned)B, 1, &run, true);
                     if (rc) { c->run_pool.push_back(mers); return rc; }
+                    hipLaunchKernelGGL(kmc_lr_addcount_kernel, dim3(1), dim3(64), 0, c->stream, (const u32*)&((const MsdCtl*)c->m_ctl.p)->n_valid, c->d_counters);
                     if (run.n) {
                         hipLaunchKernelGGL(kmc_lr_compose_kernel, dim3(grid_for(c, run.n, 256)), dim3(256), 0, c->stream, run.hi, run.lo, run.n, (const u64*)mers.lo, B);
                         HIPCHK(c, hipGetLastError());
@@ -1625,7 +1637,7 @@ extern "C" void kmc_destroy(kmc_ctx* c) {
                       &c->s_lo[0], &c->s_lo[1], &c->s_hi[0], &c->s_hi[1], &c->lr_rank, &c->a_hist, &c->a_rand, &c->a_ror,
                       &c->lg_rec, &c->lg_count, &c->lg_bins, &c->lg_cursor,
                       &c->m_hist, &c->m_stot, &c->m_bsum, &c->m_rmin, &c->m_rmax, &c->m_seg[0], &c->m_seg[1], &c->m_first, &c->m_cbase, &c->m_skip, &c->m_term, &c->m_ord,
-                      &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_w[0], &c->m_w[1],
+                      &c->m_bitmap, &c->m_rank, &c->m_nd, &c->m_base, &c->m_ctl, &c->m_clist, &c->m_w[0], &c->m_w[1],
                       &c->snap_hi, &c->snap_lo, &c->snap_cnt, &c->snap_n, &c->snap_occ, &c->rx_hi, &c->rx_lo, &c->rx_cnt};
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     sk_free(c);

@@ -105,45 +105,88 @@ void kmc_lr_mer_kernel(const uint8_t* __restrict__ bases, u64 n_bases, u64 q0, u
     rank[q - q0] = r;
 }
 
-// 3. One thread per (window start, chunk size) pair, so stores are fully coalesced: key index = 61 * (p -
-//    p_begin) + (s - 80).  Pairs that do not exist (read too short for this size, window start in the last
-//    79 bases of a read) get the all-ones filler the sort drops.  rank[] is indexed from q0.
+// 3. A workgroup forms the keys of 256 consecutive window starts, size by size: its store j writes the keys of size
+//    80 + j of all its starts (2 KB contiguous), key index = 61 * (P0 - p_begin) + j * npos + t.  (Round 2 laid a start's
+//    61 keys side by side -- 61 consecutive keys with the same left rank, i.e. the same level-0 digit: the sort's histogram
+//    and scatter kernels spent their time in same-address LDS atomics, 343 + 569 us for 71 M keys.  The sort does not care
+//    where a key starts out.)  Pairs that do not exist (read too short for this size, window start in the last 79 bases
+//    of a read) get the all-ones filler the sort drops.  rank[] is indexed from q0.
+//    The read a start lies in: ONE 64-ary search per workgroup for the read of its first start, then the following read
+//    ends from LDS (round 2: a 12-probe binary search over the offsets per thread, before the first store was issued).
 __global__ __launch_bounds__(KMC_LRX_THREADS)
 void kmc_lr_pair_kernel(const u64* __restrict__ offsets, u64 n_reads, u64 p_begin, u64 p_end, u64 q0, u64 nq, const u32* __restrict__ rank, int B,
                         u64* __restrict__ out_lo, u64* __restrict__ counters) {
     __shared__ u64 rend[KMC_LRX_POS];   // end of the read a window start lies in
+    __shared__ u64 roff[KMC_LRX_POS + 1];   // read ends behind the workgroup's first start
     __shared__ u32 rk[KMC_LRX_POS + KMC_LRX_DMAX + 1];
-    const u32 tid = threadIdx.x;
+    __shared__ u64 s_first;
+    const u32 tid = threadIdx.x, lane = tid & 63;
     const u64 P0 = p_begin + (u64)blockIdx.x * KMC_LRX_POS;
     if (P0 >= p_end) return;
     const u32 npos = (u32)min((u64)KMC_LRX_POS, p_end - P0);
-    if (tid < npos) {  // the read of my window start: last r with offsets[r] <= p  (offsets[n_reads] > p)
-        const u64 p = P0 + tid;
+    for (u32 i = tid; i < KMC_LRX_POS + KMC_LRX_DMAX + 1; i += KMC_LRX_THREADS) rk[i] = (P0 + i - q0 < nq) ? rank[P0 + i - q0] : KMC_LR_NORANK;
+    if (tid < 64) {   // wave 0: last r with offsets[r] <= P0  (offsets[0] = 0 <= P0 < offsets[n_reads])
         u64 lo_i = 0, hi_i = n_reads;
         while (hi_i - lo_i > 1) {
-            const u64 mid = (lo_i + hi_i) >> 1;
-            if (offsets[mid] <= p) lo_i = mid; else hi_i = mid;
+            const u64 step = (hi_i - lo_i + 63) / 64;
+            const u64 idx = lo_i + (u64)lane * step;
+            const bool le = idx < hi_i && offsets[idx] <= P0;
+            const u32 cnt = (u32)__popcll(__builtin_amdgcn_ballot_w64(le));   // (lane 0 always: offsets[lo_i] <= P0)
+            lo_i += (u64)(cnt - 1) * step;
+            hi_i = min(lo_i + step, hi_i);
         }
-        rend[tid] = offsets[lo_i + 1];
+        if (lane == 0) s_first = lo_i;
     }
-    for (u32 i = tid; i < KMC_LRX_POS + KMC_LRX_DMAX + 1; i += KMC_LRX_THREADS) rk[i] = (P0 + i - q0 < nq) ? rank[P0 + i - q0] : KMC_LR_NORANK;
     __syncthreads();
-    const u32 n_keys = npos * KMC_LRX_NS;
-    u64 nk = 0;
-    bool saw_bad = false;
-    for (u32 q = tid; q < n_keys; q += KMC_LRX_THREADS) {
-        const u32 t = q / KMC_LRX_NS, j = q - t * KMC_LRX_NS, sz = KMC_LR_SMIN + j;
-        u64 key = ~0ull;
-        if (P0 + t + sz <= rend[t]) {  // main.rs:73-75
-            const u32 a = rk[t], b = rk[t + sz - KMC_LR_R];
-            if (a == KMC_LR_NORANK || b == KMC_LR_NORANK) saw_bad = true;
-            else { key = ((u64)a << B) | b; nk++; }
+    const u64 rf = s_first;
+    for (u32 i = tid; i < KMC_LRX_POS + 1; i += KMC_LRX_THREADS) roff[i] = rf + 1 + i <= n_reads ? offsets[rf + 1 + i] : ~0ull;
+    __syncthreads();
+    if (tid < npos) {
+        const u64 p = P0 + tid;
+        u64 e;
+        if (roff[KMC_LRX_POS] > p) {   // first read end > p among the staged ones (sorted; roff[0] > P0)
+            u32 lo_i = 0, hi_i = KMC_LRX_POS;   // roff[hi_i] > p
+            if (roff[0] > p) hi_i = 0;
+            while (hi_i - lo_i > 1) {
+                const u32 mid = (lo_i + hi_i) >> 1;
+                if (roff[mid] > p) hi_i = mid; else lo_i = mid;
+            }
+            e = roff[hi_i];
+        } else {   // more than 256 reads end within these 256 positions (empty reads): the general search
+            u64 lo_i = rf, hi_i = n_reads;
+            while (hi_i - lo_i > 1) {
+                const u64 mid = (lo_i + hi_i) >> 1;
+                if (offsets[mid] <= p) lo_i = mid; else hi_i = mid;
+            }
+            e = offsets[lo_i + 1];
         }
-        out_lo[(P0 - p_begin) * KMC_LRX_NS + q] = key;
+        rend[tid] = e;
+    }
+    __syncthreads();
+    bool saw_bad = false;
+    if (tid < npos) {
+        const u64 pe = rend[tid], p = P0 + tid;
+        const u32 a = rk[tid];
+        u64* const o = out_lo + (P0 - p_begin) * KMC_LRX_NS + tid;
+#pragma unroll 4
+        for (u32 j = 0; j < KMC_LRX_NS; ++j) {
+            const u32 sz = KMC_LR_SMIN + j;
+            u64 key = ~0ull;
+            if (p + sz <= pe) {  // main.rs:73-75
+                const u32 b = rk[tid + sz - KMC_LR_R];
+                if (a == KMC_LR_NORANK || b == KMC_LR_NORANK) saw_bad = true;
+                else key = ((u64)a << B) | b;
+            }
+            o[(size_t)j * npos] = key;
+        }
     }
     if (saw_bad) atomicOr((unsigned long long*)&counters[KMC_CTR_ERR], 4ull);
-    nk = wave_sum_u64(nk);
-    if ((tid & 63) == 0 && nk) atomicAdd((unsigned long long*)&counters[KMC_CTR_KMERS], nk);
+}
+// The keys of a batch are counted by their sort (its number of valid keys), added to the ctx counter behind it.  (The pair
+// kernel used to add them up itself: one same-address atomic per wave, 25 k of them on the 71 M-key benchmark -- they, not
+// its 568 MB of stores, were most of its 0.3 ms.)
+__global__ void kmc_lr_addcount_kernel(const u32* __restrict__ n_valid, u64* __restrict__ counters) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) counters[KMC_CTR_KMERS] += *n_valid;
 }
 
 // 4. the sorted run's one-word keys back to {hi, lo} = L (54 bits) ++ R (54 bits)

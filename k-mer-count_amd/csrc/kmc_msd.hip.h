@@ -32,7 +32,15 @@
 #include <type_traits>
 #include "kmc_device.hip.h"
 
-#define KMC_MSD_RANGE 65536   // keys per histogram / scatter workgroup (a histogram row of 1025 counters per range)
+#define KMC_MSD_RANGE 65536   // keys per histogram / scatter workgroup (a histogram row of 1025 counters per range): what the extraction
+                              // kernel's rows cover; sorts that build their own rows take `rsz` = msd_range_for(n) instead
+// keys per range of a sort of n keys: about two thousand ranges, i.e. workgroups per pass, at least (a 1.7 M-key sort -- the
+// LR mode's dictionary -- ran its passes on 27 workgroups with 65536-key ranges: 90 us for a 14 MB histogram pass)
+static inline unsigned msd_range_for(unsigned long long n) {
+    unsigned r = 4096;
+    while (r < KMC_MSD_RANGE && (unsigned long long)r * 2048 < n) r <<= 1;
+    return r;
+}
 #define KMC_MSD_BITS 10       // digit width of a level (the last level of a key may be narrower)
 #define KMC_MSD_ND (1 << KMC_MSD_BITS)
 #define KMC_MSD_NB (KMC_MSD_ND + 1)   // digit bins + "invalid position"
@@ -60,8 +68,10 @@
 struct MsdSeg { u32 begin, len, hib, parity; };  // parity: which of the two key buffers holds the segment
 __device__ __forceinline__ int msd_seg_shift(u32 hib) { return hib > KMC_MSD_BITS ? (int)hib - KMC_MSD_BITS : 0; }
 __device__ __forceinline__ u32 msd_seg_mask(u32 hib) { return hib >= KMC_MSD_BITS ? (u32)KMC_MSD_ND - 1u : (1u << hib) - 1u; }
-// kind 0: leaf (sort in LDS); kind 1: all keys equal (one pair, key = first element)
+// kind 0: leaf (sort in LDS); kind 1: all keys equal (one pair, key = first element); kind 2 | bits << 8: a span of ANY length
+// whose keys differ in their lowest `bits` <= KMC_MSD_CNT_BITS bits only: counted in an LDS histogram (kmc_msd_count_kernel)
 struct MsdTerm { u32 begin, len, kind, parity; };
+#define KMC_MSD_CNT_BITS 14   // 2^14 u32 counters = 64 KB of LDS: two such workgroups per CU
 
 // device-side bookkeeping of one sort (all counters of a level are zeroed by the host before use)
 struct MsdCtl {
@@ -74,6 +84,8 @@ struct MsdCtl {
     u32 scan_total;  // total of the last kmc_scan_* call
     u32 pad;
     unsigned long long w_total;  // sum of all weights (weighted sorts: the merged table's total count)
+    u32 n_cnt;       // kind-2 terminals made so far (kmc_msd_scan_kernel)
+    u32 n_cnt2;      // ... listed by kmc_msd_order_kernel
     u32 n_dups[64];  // keys that repeat an earlier key of their terminal (terminal t adds to slot t % 64: one word would
                      // take 400 k same-address atomics on heavily repeated keys): pairs = valid keys - their sum
 };
@@ -165,13 +177,13 @@ void kmc_scan_final_kernel(const void* __restrict__ src, u32 n, const u32* __res
 
 // first[i] = number of ranges of segments 0..i-1; ctl->n_ranges = total.  One workgroup.
 __global__ __launch_bounds__(1024)
-void kmc_msd_ranges_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, u32* __restrict__ first, MsdCtl* ctl) {
+void kmc_msd_ranges_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, u32 rsz, u32* __restrict__ first, MsdCtl* ctl) {
     __shared__ u32 part[1024];
     const u32 tid = threadIdx.x;
     const u32 per = (n_seg + 1023) / 1024;
     const u32 a = min(tid * per, n_seg), b = min(a + per, n_seg);
     u32 s = 0;
-    for (u32 i = a; i < b; ++i) s += (seg[i].len + KMC_MSD_RANGE - 1) / KMC_MSD_RANGE;
+    for (u32 i = a; i < b; ++i) s += (seg[i].len + rsz - 1) / rsz;
     part[tid] = s;
     __syncthreads();
     for (u32 o = 1; o < 1024; o <<= 1) {
@@ -181,7 +193,7 @@ void kmc_msd_ranges_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, u32* __res
         __syncthreads();
     }
     u32 run = tid ? part[tid - 1] : 0;
-    for (u32 i = a; i < b; ++i) { first[i] = run; run += (seg[i].len + KMC_MSD_RANGE - 1) / KMC_MSD_RANGE; }
+    for (u32 i = a; i < b; ++i) { first[i] = run; run += (seg[i].len + rsz - 1) / rsz; }
     if (tid == 1023) { first[n_seg] = part[1023]; ctl->n_ranges = part[1023]; }
 }
 
@@ -200,7 +212,7 @@ template <int KW>
 __global__ __launch_bounds__(KMC_MSD_THREADS)
 void kmc_msd_hist_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo0, const u64* __restrict__ hi1, const u64* __restrict__ lo1,
                          const MsdSeg* __restrict__ seg, u32 n_seg,
-                         const u32* __restrict__ first, int kb, int level0,
+                         const u32* __restrict__ first, u32 rsz, int kb, int level0,
                          u32* __restrict__ hist, u64* __restrict__ rmin, u64* __restrict__ rmax, const MsdCtl* __restrict__ ctl) {
     __shared__ u32 h[4][KMC_MSD_NB + 3];
     __shared__ u64 smin[4][2], smax[4][2];
@@ -210,8 +222,8 @@ void kmc_msd_hist_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
     __syncthreads();
     const u32 s = msd_seg_of(first, n_seg, r);
     const u32 idx = r - first[s];
-    const u32 b = seg[s].begin + idx * KMC_MSD_RANGE;
-    const u32 n = min((u32)KMC_MSD_RANGE, seg[s].len - idx * KMC_MSD_RANGE);
+    const u32 b = seg[s].begin + idx * rsz;
+    const u32 n = min(rsz, seg[s].len - idx * rsz);
     const int shift = msd_seg_shift(seg[s].hib);
     const u32 mask = msd_seg_mask(seg[s].hib);
     const u64* const khi = seg[s].parity ? hi1 : hi0;
@@ -291,7 +303,7 @@ void kmc_msd_scan_a_kernel(u32 n_seg, u32 S, const u32* __restrict__ first, u32*
 __global__ __launch_bounds__(KMC_MSD_ND)
 void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* __restrict__ first, u32* __restrict__ hist, const u32* __restrict__ stot,
                          const u64* __restrict__ rmin, const u64* __restrict__ rmax, u32* __restrict__ cbase, u32* __restrict__ seg_skip,
-                         int level0, u32 leaf_cap,
+                         int level0, int wide, u32 leaf_cap, u32 cnt_bits,
                          MsdSeg* __restrict__ next, u32 next_cap, MsdTerm* __restrict__ term, u32 term_cap,
                          unsigned long long* __restrict__ bitmap, MsdCtl* ctl) {
     constexpr int NWV = KMC_MSD_ND / 64;
@@ -368,40 +380,51 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
     //   - otherwise its children, in position order: large ones go on to the next level (or, with no bits
     //     left, are one pair each); runs of consecutive small ones are merged into leaves of at most
     //     leaf_cap keys (a leaf sorts whatever keys it holds, so it need not be a single child)
+    //   `wide` (the host sets it while a level has a handful of segments -- level 0 is ONE): every wave walks its own
+    //   64 digits and keeps its own lists (leaves are then not merged across a multiple of 64 digits).  A lone wave
+    //   issues an instruction every four or five cycles: the walk over 1024 occupied digits took 83-98 us per level-0
+    //   scan, as much as the LR mode's whole dictionary histogram.
     __shared__ u32 l_tb[KMC_MSD_ND], l_tl[KMC_MSD_ND], l_tk[KMC_MSD_ND], l_nb[KMC_MSD_ND], l_nl[KMC_MSD_ND];
-    if (wv != 0) return;
     const bool nomove = !equal && !last_level && top_diff >= 0 && top_diff < shift && n_filler == 0;
-    if (lane == 0) {
+    if (wv != 0 && (!wide || equal || nomove)) return;
+    const u32 lb = wide ? wv * 64u : 0u;   // this wave's part of the lists
+    if (tid == 0) {
         cbase[(size_t)s * KMC_MSD_NB + KMC_MSD_ND] = 0;
         seg_skip[s] = (equal || nomove) ? 1u : 0u;
         if (level0) ctl->n_valid = seg[s].len - n_filler;
     }
-    u32 nt = 0, nn = 0;
+    u32 nt = 0, nn = 0, ncnt = 0;
     u32 q_hib = (u32)shift, q_par = src_parity ^ 1u, t_par = src_parity ^ 1u;
     if (equal) {
         if (lane == 0) { l_tb[0] = seg[s].begin; l_tl[0] = seg[s].len; l_tk[0] = 1u; }
         nt = 1; t_par = src_parity;
+    } else if (nomove && cnt_bits && (u32)(top_diff + 1) <= cnt_bits && seg[s].len > leaf_cap) {
+        // its keys differ in a few low bits only: counted where it lies, however long it is
+        if (lane == 0) { l_tb[0] = seg[s].begin; l_tl[0] = seg[s].len; l_tk[0] = 2u | ((u32)(top_diff + 1) << 8); }
+        nt = 1; ncnt = 1; t_par = src_parity;
     } else if (nomove) {
         if (lane == 0) { l_nb[0] = seg[s].begin; l_nl[0] = seg[s].len; }
         nn = 1; q_hib = (u32)(top_diff + 1); q_par = src_parity;
     } else {
-        u32 T[NWV], C[NWV];
-#pragma unroll
-        for (int j = 0; j < NWV; ++j) { T[j] = tot[j * 64 + lane]; C[j] = cb_s[j * 64 + lane]; }
         u32 gb = 0, gl = 0;
-        auto flush = [&]() { if (lane == 0) { l_tb[nt] = gb; l_tl[nt] = gl; l_tk[nt] = gl == 1 ? 1u : 0u; } ++nt; gl = 0; };
-#pragma unroll
-        for (int j = 0; j < NWV; ++j) {
-            unsigned long long live = __builtin_amdgcn_ballot_w64(T[j] != 0);
+        auto flush = [&]() { if (lane == 0) { l_tb[lb + nt] = gb; l_tl[lb + nt] = gl; l_tk[lb + nt] = gl == 1 ? 1u : 0u; } ++nt; gl = 0; };
+        const int jb = wide ? (int)wv : 0, je = wide ? (int)wv + 1 : NWV;
+        for (int j = jb; j < je; ++j) {
+            const u32 Tj = tot[j * 64 + lane], Cj = cb_s[j * 64 + lane];
+            unsigned long long live = __builtin_amdgcn_ballot_w64(Tj != 0);
             while (live) {
                 const int bl = (int)__builtin_ctzll(live);
                 live &= live - 1;
-                const u32 m = (u32)__builtin_amdgcn_readlane((int)T[j], bl);
-                const u32 cbv = (u32)__builtin_amdgcn_readlane((int)C[j], bl);
+                const u32 m = (u32)__builtin_amdgcn_readlane((int)Tj, bl);
+                const u32 cbv = (u32)__builtin_amdgcn_readlane((int)Cj, bl);
                 if (m > leaf_cap) {
                     if (gl) flush();
-                    if (last_level) { if (lane == 0) { l_tb[nt] = cbv; l_tl[nt] = m; l_tk[nt] = 1u; } ++nt; }
-                    else { if (lane == 0) { l_nb[nn] = cbv; l_nl[nn] = m; } ++nn; }
+                    if (last_level) { if (lane == 0) { l_tb[lb + nt] = cbv; l_tl[lb + nt] = m; l_tk[lb + nt] = 1u; } ++nt; }
+                    else if (cnt_bits && (u32)shift <= cnt_bits) {   // few bits left, many keys: no further level, an LDS histogram
+                        if (lane == 0) { l_tb[lb + nt] = cbv; l_tl[lb + nt] = m; l_tk[lb + nt] = 2u | ((u32)shift << 8); }
+                        ++nt; ++ncnt;
+                    }
+                    else { if (lane == 0) { l_nb[lb + nn] = cbv; l_nl[lb + nn] = m; } ++nn; }
                 } else {
                     if (gl && gl + m > leaf_cap) flush();
                     if (!gl) gb = cbv;
@@ -415,6 +438,7 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
     if (lane == 0) {
         if (nt) { t_base = atomicAdd(&ctl->n_term, nt); if (t_base + nt > term_cap) atomicOr(&ctl->overflow, 1u); }
         if (nn) { n_base = atomicAdd(&ctl->n_next, nn); if (n_base + nn > next_cap) atomicOr(&ctl->overflow, 2u); }
+        if (ncnt) atomicAdd(&ctl->n_cnt, ncnt);
     }
     t_base = (u32)__builtin_amdgcn_readfirstlane((int)t_base);
     n_base = (u32)__builtin_amdgcn_readfirstlane((int)n_base);
@@ -423,13 +447,13 @@ void kmc_msd_scan_kernel(const MsdSeg* __restrict__ seg, u32 n_seg, const u32* _
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     for (u32 i = lane; i < nt; i += 64) {
         if (t_base + i >= term_cap) break;
-        const u32 bg = l_tb[i];
-        term[t_base + i] = MsdTerm{bg, l_tl[i], l_tk[i], t_par};
+        const u32 bg = l_tb[lb + i];
+        term[t_base + i] = MsdTerm{bg, l_tl[lb + i], l_tk[lb + i], t_par};
         atomicOr(&bitmap[bg >> 6], 1ull << (bg & 63));
     }
     for (u32 i = lane; i < nn; i += 64) {
         if (n_base + i >= next_cap) break;
-        next[n_base + i] = MsdSeg{l_nb[i], l_nl[i], q_hib, q_par};
+        next[n_base + i] = MsdSeg{l_nb[lb + i], l_nl[lb + i], q_hib, q_par};
     }
 }
 
@@ -462,7 +486,7 @@ template <int KW, bool WEIGHTS>
 __global__ __launch_bounds__(1024)
 void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* __restrict__ w0,
                             u64* __restrict__ hi1, u64* __restrict__ lo1, u64* __restrict__ w1,
-                            const MsdSeg* __restrict__ seg, u32 n_seg, const u32* __restrict__ first,
+                            const MsdSeg* __restrict__ seg, u32 n_seg, const u32* __restrict__ first, u32 rsz,
                             const u32* __restrict__ hist, const u32* __restrict__ cbase, const u32* __restrict__ seg_skip,
                             int kb, int level0, const MsdCtl* __restrict__ ctl) {
     extern __shared__ __align__(16) unsigned char msd_smem[];
@@ -484,8 +508,8 @@ void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* _
     u64* const ow = sp ? w0 : w1;
     for (u32 d = tid; d < KMC_MSD_NB; d += 1024) L.cur[d] = cbase[(size_t)s * KMC_MSD_NB + d] + hist[msd_hist_idx(r, d)];
     const u32 idx = r - first[s];
-    const u32 b = seg[s].begin + idx * KMC_MSD_RANGE;
-    const u32 n = min((u32)KMC_MSD_RANGE, seg[s].len - idx * KMC_MSD_RANGE);
+    const u32 b = seg[s].begin + idx * rsz;
+    const u32 n = min(rsz, seg[s].len - idx * rsz);
     // the keys of the first tile; every later tile is loaded while the one before it goes through LDS.
     // A tile comes in as ALIGNED PAIRS (16 bytes per lane and load, 1 KiB per wave instruction): register slot s of the
     // workgroup (thread t: slots 2 (t + 1024 e) + {0, 1}) holds key s + off of the tile, off = parity of the tile's first
@@ -596,12 +620,70 @@ void kmc_msd_scatter_kernel(u64* __restrict__ hi0, u64* __restrict__ lo0, u64* _
 }
 
 // ordered[t] = the terminal whose begin has ordinal t (rank = exclusive popcount prefix of the bitmap words)
+// (and the kind-2 terminals' ordinals listed in clist, for kmc_msd_count_kernel)
 __global__ void kmc_msd_order_kernel(const MsdTerm* __restrict__ term, u32 n_term, const unsigned long long* __restrict__ bitmap,
-                                     const u32* __restrict__ rank, MsdTerm* __restrict__ ordered) {
+                                     const u32* __restrict__ rank, MsdTerm* __restrict__ ordered, u32* __restrict__ clist, MsdCtl* ctl) {
     for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n_term; i += gridDim.x * blockDim.x) {
         const u32 p = term[i].begin;
         const unsigned long long below = bitmap[p >> 6] & ((1ull << (p & 63)) - 1ull);
-        ordered[rank[p >> 6] + (u32)__popcll(below)] = term[i];
+        const u32 o = rank[p >> 6] + (u32)__popcll(below);
+        ordered[o] = term[i];
+        if ((term[i].kind & 0xFFu) == 2u) clist[atomicAdd(&ctl->n_cnt2, 1u)] = o;
+    }
+}
+
+// ---- kind-2 terminals: an LDS histogram over the bits that are left ---------------------------------------------
+// One workgroup per listed terminal: every key adds one to counter [key & mask]; the non-zero counters, in order, are the
+// terminal's (key, count) pairs -- written to the run at the terminal's own positions like a leaf's (there are never
+// more pairs than keys).  What it replaces: the LR mode's rank pairs are 2 * log2(distinct 27-mers) bits long, 24 on the
+// 4000-record benchmark, so after ONE level every segment still held 70 k keys of 14 bits: a second and a third level
+// (0.79 + 0.09 ms for 71 M keys) and leaves full of repeated keys (0.88 ms) did what 64 KB of counters do in one read.
+template <int KW>
+__global__ __launch_bounds__(1024)
+void kmc_msd_count_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo0, const u64* __restrict__ hi1, const u64* __restrict__ lo1,
+                          const MsdTerm* __restrict__ term, const u32* __restrict__ clist, u32 n_list,
+                          u64* __restrict__ o_hi, u64* __restrict__ o_lo, u64* __restrict__ o_cnt, u32* __restrict__ nd, MsdCtl* __restrict__ ctl) {
+    __shared__ u32 cnt[1u << KMC_MSD_CNT_BITS];
+    __shared__ u32 wsum[16];
+    const u32 tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (blockIdx.x >= n_list) return;
+    const u32 t = clist[blockIdx.x];
+    const MsdTerm T = term[t];
+    const u32 bits = T.kind >> 8, nbin = 1u << bits, n = T.len;
+    const u64 mask = (u64)nbin - 1ull;
+    const u64* const klo = (T.parity ? lo1 : lo0) + T.begin;
+    for (u32 i = tid; i < nbin; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    u32 i = tid;
+    for (; i + 3 * 1024 < n; i += 4 * 1024) {   // four loads in flight per thread
+        const u64 a = klo[i], b = klo[i + 1024], c = klo[i + 2048], d = klo[i + 3072];
+        atomicAdd(&cnt[(u32)(a & mask)], 1u); atomicAdd(&cnt[(u32)(b & mask)], 1u);
+        atomicAdd(&cnt[(u32)(c & mask)], 1u); atomicAdd(&cnt[(u32)(d & mask)], 1u);
+    }
+    for (; i < n; i += 1024) atomicAdd(&cnt[(u32)(klo[i] & mask)], 1u);
+    const u64 plo = klo[0] & ~mask;   // what all keys share
+    const u64 phi = KW == 2 ? ((T.parity ? hi1 : hi0)[T.begin]) : 0ull;
+    __syncthreads();
+    // thread t owns the bins [t * per, (t + 1) * per): its non-zero ones, in order, behind those of the threads before it
+    const u32 per = nbin >= 1024 ? nbin / 1024 : 1u;
+    const u32 b0 = tid * per;
+    u32 mine = 0;
+    if (b0 < nbin) for (u32 e = 0; e < per; ++e) mine += cnt[b0 + e] ? 1u : 0u;
+    u32 inc = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const u32 v = __shfl_up(inc, o); if ((int)lane >= o) inc += v; }
+    if (lane == 63) wsum[wv] = inc;
+    __syncthreads();
+    u32 base = 0, total = 0;
+    for (u32 w = 0; w < 16; ++w) { if (w < wv) base += wsum[w]; total += wsum[w]; }
+    u32 r = T.begin + base + inc - mine;
+    if (b0 < nbin) for (u32 e = 0; e < per; ++e) {
+        const u32 c = cnt[b0 + e];
+        if (c) { o_lo[r] = plo | (u64)(b0 + e); if (KW == 2) o_hi[r] = phi; o_cnt[r] = c; ++r; }
+    }
+    if (tid == 0) {
+        nd[t] = total;
+        if (total != n) atomicAdd(&ctl->n_dups[t & 63u], n - total);
     }
 }
 
@@ -688,6 +770,7 @@ void kmc_msd_leaf_kernel(const u64* __restrict__ hi0, const u64* __restrict__ lo
             }
         }
     };
+    if ((T.kind & 0xFFu) == 2u) return;   // (kmc_msd_count_kernel's)
     if (T.kind == 1) {  // all keys equal: one pair
         u64 s = n;
         if (WEIGHTS) {

@@ -537,6 +537,13 @@ void kmc_walk_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64* 
     // tiles dealt in chunks of 16, the ticket drawn two chunks ahead by the wave that takes a chunk's first tile and issued
     // right in front of its step phase, so that nothing ever waits for it -- exact, and 3 % SLOWER at 10 GB (1.393 vs
     // 1.352 ms) and 2 % slower at 1 GB: whatever spreads the XCDs' finish times, it is not a shortage of tiles.)
+    // (Round 3, the end of a workgroup's queue: a wave draws its next tile at the entry of the one before, so whoever draws
+    // the last ticket has up to two tiles to go while the others leave -- stamps (tools/walk_stamps.py) show the waves of a
+    // workgroup leaving 27 us apart (median; up to 47) at 16 us a tile, a seventh of the kernel on the 1 GB batch of
+    // BASELINE config 2.  Dealing the last 4 / 8 / 16 tiles of a workgroup in halves, quarters or eighths (16 .. 8 reads per
+    // draw) brought that to 13 us -- and made the kernel SLOWER, 0.200-0.223 vs 0.196 ms at 1 GB and 1.35-1.37 vs 1.345 at
+    // 10 GB: a tile's time is its chain of 25 dependent steps, which is as long for 16 reads as for 64.
+    // profiles/r03_walk_tail_split_ab.txt.)
     auto tile_of = [&](u32 j) { return tile_begin + blockIdx.x + (u64)gridDim.x * j; };
     const u64 gw = tile_of((u32)wv);  // the first tile of every wave is fixed; the counter starts behind them
 
