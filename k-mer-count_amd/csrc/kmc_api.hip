@@ -129,6 +129,11 @@ struct kmc_ctx {
     kmc_stats st{};
     int fin_parity = 0;    // which OUT/SUM counter pair the next kmc_finalize uses
     u64 fin_hint = 0;      // table entries at the last kmc_finalize (sizes the next speculative small-table finalize)
+    // The rank sort of kmc_small_finalize_kernel is quadratic: 16 us for 1 k keys, 0.24 ms for 24 k, 0.8 ms for 68 k (measured).  The
+    // weighted radix sort that larger tables take costs 0.25-0.3 ms at that size (a dozen small launches, two polls): tables
+    // that were larger than this at the last finalize go there directly.  (KMC_FIN_SMALL_MAX overrides: the parity test of
+    // the kernel's size boundaries runs it up to its limit, KMC_OCC_LIST_CAP.)
+    u64 fin_small_max = 40000;
     bool batch_pending = false;  // a COUNT kernel (unknown number of new keys) is queued since the last poll
     u64 unpolled_adds = 0;       // upper bound of keys added by merge kernels since the last poll
     bool walk_overflowed = false;  // the last WALK/STREAM launches counted >5% of their k-mers with global atomics
@@ -1665,6 +1670,7 @@ static int kmc_create_impl(kmc_ctx** out, const kmc_config* cfg) {
     c->cfg = *cfg;
     if (cfg->mode == KMC_MODE_LR) { c->KW = 2; c->klen = 54; c->cfg.k = 54; c->cfg.canonical = 0; }
     else { c->KW = cfg->k <= 31 ? 1 : 2; c->klen = cfg->k; }
+    if (const char* e = getenv("KMC_FIN_SMALL_MAX")) c->fin_small_max = std::min<u64>(strtoull(e, nullptr, 10), KMC_OCC_LIST_CAP);
     int rc = KMC_OK;
     auto body = [&]() -> int {
         HIPCHK(c, hipSetDevice(cfg->device));
@@ -1836,7 +1842,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     }
     rc = flush_acc(c);  // keys the sort path has extracted since the last flush: one run
     if (rc) return rc;
-    if (c->runs.empty()) {
+    if (c->runs.empty() && c->fin_hint <= c->fin_small_max) {
         // speculative small-table finalize, queued behind whatever is still running
         const size_t fb = (size_t)KMC_OCC_LIST_CAP * sizeof(u64);
         rc = ensure(c, c->o_lo, fb); if (rc) return rc;
@@ -1872,7 +1878,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     }
     c->fin_hint = c->h_counters[KMC_CTR_OCCUPIED];
     if (tried_fast && c->runs.empty() && c->h_counters[KMC_CTR_FASTFIN] != 1 && c->h_counters[KMC_CTR_SPILL] == 0 &&
-        c->h_counters[KMC_CTR_OCCUPIED] > (u64)fgrid_used * KMC_FIN_CHUNK && c->h_counters[KMC_CTR_OCCUPIED] <= KMC_OCC_LIST_CAP) {
+        c->h_counters[KMC_CTR_OCCUPIED] > (u64)fgrid_used * KMC_FIN_CHUNK && c->h_counters[KMC_CTR_OCCUPIED] <= c->fin_small_max) {
         // the table outgrew the speculative grid (first finalize of a larger source): once more, full grid
         fgrid_used = KMC_OCC_LIST_CAP / KMC_FIN_CHUNK;
         rc = launch_small_finalize(c, fgrid_used);

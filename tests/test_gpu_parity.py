@@ -293,16 +293,19 @@ def test_device_resident_batches_and_synth(kmc, oracle):
                 assert np.array_equal(t2.count, want.count * 2) and np.array_equal(t2.key_lo, want.key_lo)
 
 
-def test_small_table_finalize_sizes(kmc):
+@pytest.mark.parametrize("small_max", [None, "131072"])
+def test_small_table_finalize_sizes(kmc, monkeypatch, small_max):
     """The rank-sort finalize of small tables at its size boundaries (16 keys per workgroup of 1024 threads, the
     table through LDS in tiles of 4096 / 2048 keys, at most 131072 keys; 131073 takes the weighted radix sort), one-
     and two-word keys, repeated on the same ctx (the kernel drains the table and must leave its ticket clean; a
-    table that outgrew the speculative grid is finalized again with the full one)."""
+    table that outgrew the speculative grid is finalized again with the full one).  Once with the library's own
+    cut-over to the radix sort (40 k keys: the rank sort is quadratic) and once with the kernel run up to its limit."""
     torch = pytest.importorskip("torch")
+    if small_max: monkeypatch.setenv("KMC_FIN_SMALL_MAX", small_max)
     rng = np.random.default_rng(55)
     for k in (31, 63):
         with kmc.KmerCounter(k=k) as kc:
-            for n in (1, 2, 15, 16, 17, 63, 64, 65, 127, 1023, 1024, 1025, 2047, 2048, 2049, 3350, 4096, 4097, 8191, 8192, 8193, 20000, 32767, 32768, 32769, 70000, 131071, 131072, 131073, 200000, 64):
+            for n in (1, 2, 15, 16, 17, 63, 64, 65, 127, 1023, 1024, 1025, 2047, 2048, 2049, 3350, 4096, 4097, 8191, 8192, 8193, 20000, 32767, 32768, 32769, 39999, 40000, 40001, 70000, 131071, 131072, 131073, 200000, 64):
                 lo = rng.integers(0, 2**62, n, dtype=np.uint64)
                 hi = rng.integers(0, 2**60, n, dtype=np.uint64) if k > 31 else np.zeros(n, np.uint64)
                 if k > 31:
@@ -1226,3 +1229,30 @@ def test_finalize_async_small_tables(kmc, oracle):
         kc.finalize_async()
         both = oracle.count_kmers(np.concatenate([hb, hb0]), np.concatenate([ho, ho0[1:] + ho[-1]]).astype(np.uint64), 31, True, method=1)
         assert kc.export().equals(both)
+
+
+def test_msd_sort_counted_spans(kmc, oracle):
+    """Spans of MORE keys than a leaf holds whose keys differ in their last <= 14 bits only end the MSD sort in an LDS
+    histogram (kmc_msd.hip.h: kind-2 terminals, kmc_msd_count_kernel) instead of further levels + leaves: short keys
+    (k = 8: 6 bits left after one level, fewer bins than threads; k = 12: 14 bits, the widest), a segment that is not
+    moved because all its keys share the level's digit (poly-A reads that differ in their last seven bases), and the LR
+    mode's rank pairs on the benchmark generator's reads (24-bit keys).  All against the oracle."""
+    rng = np.random.default_rng(5)
+    for k, n_rec in ((8, 20_000), (12, 12_000)):
+        hb, ho = kmc.synth_reads_host(kmc.Synth(seed=4, pool=0), 0, n_rec)
+        for canonical in (True, False):
+            with kmc.KmerCounter(k=k, canonical=canonical, algo=kmc.ALGO_SORT) as kc:
+                kc.add_batch(hb, ho)
+                assert kc.export().equals(oracle.count_kmers(hb, ho, k, canonical, method=1)), (k, canonical)
+    n_rec, rl = 5000, 100
+    reads = np.full((n_rec, rl), ord("A"), dtype=np.uint8)
+    reads[:, rl - 7:] = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=(n_rec, 7))]
+    hb, ho = reads.reshape(-1).copy(), np.arange(n_rec + 1, dtype=np.uint64) * rl
+    for k in (31, 40):
+        with kmc.KmerCounter(k=k, canonical=False, algo=kmc.ALGO_SORT) as kc:
+            kc.add_batch(hb, ho)
+            assert kc.export().equals(oracle.count_kmers(hb, ho, k, False, method=1)), k
+    hb, ho = kmc.synth_reads_host(kmc.Synth(seed=2), 0, 600)
+    with kmc.KmerCounter(mode=kmc.MODE_LR) as kc:
+        kc.add_batch(hb, ho)
+        assert kc.export().equals(oracle.count_lr(hb, ho))
