@@ -58,9 +58,7 @@ def main():
     ap.add_argument("--no-weak", action="store_true", help="N>1 default run: skip the weak-scaling sub-measurement")
     ap.add_argument("--no-read-peak", action="store_true", help="skip the measured streaming-read peak (kmc_read_peak_device)")
     ap.add_argument("--reduce-finalize-every", type=int, default=5,
-                    help="the host looks at a step's result (one synchronisation + the every-step-delivered check) only every n-th step.  N = 1 "
-                         "(small tables counted in one launch): every step queues reset -> count -> finalize (kmc_finalize_async).  "
-                         "N > 1: the host looks at the owner's result only "
+                    help="N > 1: the host looks at the owner's result (one synchronisation + the every-step-delivered check) only "
                          "every n-th step; EVERY step queues count -> pack -> all-gather -> merge -> finalize of the owned partition "
                          "(kmc_finalize_async: the sorted table is produced on the device each step).  1: synchronise every step")
     ap.add_argument("--no-exact-check", action="store_true", help="skip the exact full-size table check after the timed region")
@@ -144,25 +142,9 @@ def main():
                                      f"{st.n_async_slabs_skipped - seen['skip']} oversize slabs: rerun with --reduce-finalize-every 1")
             seen.update(ok=st.n_async_ok, skip=st.n_async_slabs_skipped, steps=0)
 
-        # N = 1: what N > 1 does (above), without the exchange -- once the warm-up has shown a small table counted in one
-        # launch, every step still queues count + finalize (its sorted table lies on the device), but the host waits for it
-        # and looks at it only every `every`-th step and at the last one.  Decided per workload, after the synchronous warm-up steps.
-        pipe = {"on": False, "ok": 0, "queued": 0}
-
-        def check_kc():
-            st = kc.stats()
-            if st.n_async_ok - pipe["ok"] != pipe["queued"] or st.n_async_slabs_skipped != 0:
-                raise SystemExit(f"{pipe['queued']} steps queued, {st.n_async_ok - pipe['ok']} delivered a sorted table: rerun with --reduce-finalize-every 1")
-            pipe.update(ok=st.n_async_ok, queued=0)
-
         def step(i, last):
             kc.reset()
             kc.add_batch_device(pb, po, n_rec, n_bases, read_len)
-            if world == 1 and pipe["on"]:
-                pipe["queued"] += 1   # (every step's finalize kernel, waited for or not, counts as one delivery)
-                if not (last or (i + 1) % every == 0):
-                    kc.finalize_async()
-                    return None
             if world > 1:
                 owner.reset()
                 with torch.cuda.stream(side):
@@ -178,18 +160,11 @@ def main():
             nd, nt = kc.finalize()
             if nt != n_kmers:
                 raise SystemExit(f"count mismatch: table sums to {nt}, expected {n_kmers}")
-            if pipe["on"]:
-                check_kc()
             return nd
 
         if world > 1:
             check_owner()   # (baseline: nothing is queued on `owner` at this point, its stats are current)
         for i in range(args.warmup):
-            if world == 1 and every > 1 and not pipe["on"] and i >= 1 and i >= args.warmup - 2:
-                # the last two warm-up steps already run the way the timed ones will
-                st = kc.stats()
-                if st.launches_last == 1 and 0 < st.n_distinct <= 32768:
-                    pipe.update(on=True, ok=st.n_async_ok, queued=0)
             step(i, i == args.warmup - 1)
         fence()
         s0 = kc.stats()
@@ -205,17 +180,6 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         s1 = kc.stats()   # (reads the launch events of every batch since s0: kernel_ms_lifetime survives kmc_reset)
-        sync_ms = None
-        pipelined = pipe["on"]
-        if pipelined:   # outside the timed region: the same steps with the host waiting for every one of them
-            pipe["on"] = False   # (and everything after this runs that way)
-            ns_ = min(args.steps, 10)
-            fence()
-            ts = time.perf_counter()
-            for i in range(ns_):
-                step(i, True)
-            fence()
-            sync_ms = (time.perf_counter() - ts) / ns_ * 1e3
         n_l = max(int(s1.launches_lifetime - s0.launches_lifetime), 1)
         k_ms = (s1.kernel_ms_lifetime - s0.kernel_ms_lifetime) / args.steps
         algo_used = {1: "stream", 2: "walk", 3: "sort"}.get(s1.algo_last, "?")
@@ -271,7 +235,7 @@ def main():
         res = {"seed": seed, "strong": strong, "fasta_bytes": fasta_bytes, "n_rec": n_rec, "n_all": n_all, "n_bases": n_bases, "n_kmers": n_kmers,
                "n_kmers_all": n_kmers_all, "elapsed": elapsed, "kernel_ms": k_ms, "launches_per_step": n_l / args.steps, "algo_used": algo_used,
                "cold_ms": cold_ms, "exact_full": exact_full, "reduced": reduced, "nd": nd, "read_peak": peak, "read_len": read_len,
-               "first": first, "synth": synth, "pipelined": pipelined, "sync_ms": sync_ms}
+               "first": first, "synth": synth}
         del d_bases, d_offs
         torch.cuda.empty_cache()
         return res
@@ -393,12 +357,6 @@ def main():
                "distinct": int(reduced["distinct_all_owners"]) if reduced else int(m["nd"]), "algo": algo_used,
                "sharding": "records, one shard per GPU; RCCL table reduce (one all-gather of fixed-size slabs)" if world > 1 else "single GPU",
                "reduced": reduced, "exact_full_size_check": m["exact_full"]}
-        if world == 1 and m["pipelined"]:
-            cfg["host_sync_every"] = every
-            cfg["every_step_delivers"] = ("every step queues reset -> count -> unfold -> finalize (the sorted table lies on the device after each step); the "
-                                          "host waits for and checks the result (table total, n_async_ok, n_async_slabs_skipped) every %d steps and at the "
-                                          "last step; --reduce-finalize-every 1 waits for every step" % every)
-            cfg["ms_per_step_host_sync_every_step"] = round(m["sync_ms"], 4)
         if world > 1:
             cfg["reduce_finalize_every"] = every
             cfg["every_step_delivers"] = ("every step queues count -> pack -> all-gather -> merge -> finalize of the owned partition (sorted table on the "

@@ -1055,8 +1055,8 @@ int recover_overflow(kmc_ctx* c) {
         }
         if (n_snap == ~0ull) return fail(c, KMC_ERR_CAPACITY, "count table and spill area exhausted and the table could not be restored; raise capacity_hint");
         const int grid = reset_grid(c);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
-        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, sk_table_of(c), c->fin_rank + 3);
+        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, sk_table_of(c), c->fin_rank + 3);
         ctr[KMC_CTR_OCCUPIED] = 0;  // (the merge below claims the slots again and counts them)
         HIPCHK(c, hipMemcpyAsync(c->d_counters, ctr, sizeof(ctr), hipMemcpyHostToDevice, c->stream));
         if (n_snap) {
@@ -1102,8 +1102,8 @@ int recover_overflow(kmc_ctx* c) {
 int drop_batch_from_table(kmc_ctx* c, const u64* ctr0) {
     GTable g = gtable_of(c, c->tab);
     const int grid = reset_grid(c);
-    if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
-    else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
+    if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, sk_table_of(c), c->fin_rank + 3);
+    else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, sk_table_of(c), c->fin_rank + 3);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(c->d_counters, ctr0, KMC_CTR_N * sizeof(u64), hipMemcpyHostToDevice, c->stream));
     { int rs = sk_clear(c); if (rs) return rs; }
@@ -1719,11 +1719,11 @@ static int kmc_reset_impl(kmc_ctx* c) {
         // as it was -- the reset kernel decides on the device, nothing waits
         c->async_fin = false;
         c->drained = false;
-        c->sk_dirty = false;   // (kmc_finalize_async queued the unfold in front of its kernel)
+        c->sk_dirty = false;   // (kmc_finalize_async queued the unfold in front of its kernel, or the reset kernel drops what is pending)
         GTable g = gtable_of(c, c->tab);
         const int grid = reset_grid(c);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
-        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, sk_table_of(c), c->fin_rank + 3);
+        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, sk_table_of(c), c->fin_rank + 3);
         HIPCHK(c, hipGetLastError());
         c->fin_parity = 0;
     } else if (c->drained) {
@@ -1732,11 +1732,13 @@ static int kmc_reset_impl(kmc_ctx* c) {
         c->drained = false;
         c->fin_parity = 0;
     } else {
-        if (c->sk_dirty) { int r = flush_sk(c); if (r) return r; }  // (empties the (k+16)-mer table; its counts go with the table)
+        // (counts pending in the (k+16)-mer table go with the table: the reset kernel clears them, nothing is unfolded first)
+        c->sk_dirty = false;
+        if (c->sk_grow) { int r = sk_regrow(c); if (r) return r; }
         GTable g = gtable_of(c, c->tab);
         const int grid = reset_grid(c);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
-        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, c->fin_rank + 3);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_reset_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, sk_table_of(c), c->fin_rank + 3);
+        else hipLaunchKernelGGL(kmc_reset_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, sk_table_of(c), c->fin_rank + 3);
         HIPCHK(c, hipGetLastError());
         c->fin_parity = 0;
     }
@@ -1983,7 +1985,11 @@ static int kmc_finalize_async_impl(kmc_ctx* c) {
     int rc = ensure(c, c->o_lo, fb); if (rc) return rc;
     rc = ensure(c, c->o_cnt, fb); if (rc) return rc;
     if (c->KW == 2) { rc = ensure(c, c->o_hi, fb); if (rc) return rc; }
-    if (c->sk_dirty) { rc = flush_sk(c); if (rc) return rc; }
+    // Pending (k+16)-mer counts have to be in the table first.  Only the device knows whether there are any; while no poll has
+    // ever seen that table in use on this source (sklog_on), none are expected and nothing is launched for them: the kernel
+    // below checks, and gives up if the guess was wrong -- the next synchronising call then finalizes the ordinary way, and a
+    // kmc_reset in between throws those counts away with the table (kmc_reset_kernel).
+    if (c->sk_dirty && c->sklog_on) { rc = flush_sk(c); if (rc) return rc; }
     // (no second try here as in kmc_finalize: room for 8192 keys at least, whatever the last table looked like)
     rc = launch_small_finalize(c, std::max(small_finalize_grid(c), 8192 / KMC_FIN_CHUNK));
     if (rc) return rc;
@@ -2076,14 +2082,15 @@ static int kmc_pack_slab_device_impl(kmc_ctx* c, void* d_slab, uint64_t slab_ent
     if (((uintptr_t)d_slab & 7) != 0) return fail(c, KMC_ERR_ARG, "d_slab must be 8-byte aligned");
     HIPCHK(c, hipSetDevice(c->cfg.device));
     { int rc = resolve_async(c); if (rc) return rc; }
-    if (c->sk_dirty) { int r = flush_sk(c); if (r) return r; }
+    if (c->sk_dirty && (c->sklog_on || c->sorted_valid)) { int r = flush_sk(c); if (r) return r; }   // (else: none expected -- the pack kernel checks)
     if (!c->sorted_valid) {
         // not finalized: pack the live table (unsorted) -- the device decides whether it fits
         GTable g = gtable_of(c, c->tab);
+        const u64* skc = c->sk.lo ? c->d_counters + KMC_CTR_N : nullptr;
         const int force = (c->runs.empty() && !c->acc_n) ? 0 : 1;  // sorted runs / extracted keys exist only for high-cardinality input: far too large
         const int grid = grid_for(c, std::min<u64>(slab_entries, KMC_OCC_LIST_CAP), 256);
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_pack_slab_live_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, (u64)slab_entries, force, (u64*)d_slab);
-        else hipLaunchKernelGGL(kmc_pack_slab_live_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, (u64)slab_entries, force, (u64*)d_slab);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_pack_slab_live_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, skc, (u64)slab_entries, force, (u64*)d_slab);
+        else hipLaunchKernelGGL(kmc_pack_slab_live_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, skc, (u64)slab_entries, force, (u64*)d_slab);
         HIPCHK(c, hipGetLastError());
         return KMC_OK;
     }

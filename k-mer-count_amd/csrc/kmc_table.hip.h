@@ -57,8 +57,16 @@ void kmc_compact_kernel(GTable g, u64* out_hi, u64* out_lo, u64* out_cnt, u64* o
 // without waiting, kmc_finalize_async, drains it when it succeeds and the host cannot know), anything else is cleared
 // slot by slot.  Every workgroup must see the SAME counters, so they are cleared by the workgroup that draws the last
 // ticket of *done (zero between launches), after all have read them.
+// sk: the (k+16)-mer table of the walk path (kmc_walk.hip.h) or an empty GTable.  Counts still pending there belong to the
+// batches that are being thrown away: they are cleared with the table (keys stay), so that a caller who queues
+// finalize -> reset -> next batch without ever waiting needs no separate unfold launch in between.
 template <int KW>
-__global__ void kmc_reset_kernel(GTable g, u32* done) {
+__global__ void kmc_reset_kernel(GTable g, GTable sk, u32* done) {
+    const bool sk_pending = sk.key_lo != nullptr && sk.counters[KMC_CTR_KMERS] != 0;
+    if (sk_pending) {
+        const u64 n_occ = min(sk.counters[KMC_CTR_OCCUPIED], sk.occ_list_cap);
+        for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n_occ; i += (u64)gridDim.x * blockDim.x) sk.count[sk.occ_list[i]] = 0;
+    }
     const u64 cap = g.capmask + 1;
     const u64 n = g.counters[KMC_CTR_OCCUPIED];
     const bool listed = n <= g.occ_list_cap && g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0;
@@ -81,6 +89,7 @@ __global__ void kmc_reset_kernel(GTable g, u32* done) {
     if (s_last) {
         if (threadIdx.x < KMC_CTR_N) g.counters[threadIdx.x] = 0;
         if (threadIdx.x == 0) *done = 0;
+        if (sk_pending && threadIdx.x == 0) { sk.counters[KMC_CTR_SPILL] = 0; sk.counters[KMC_CTR_KMERS] = 0; }
     }
 }
 
@@ -215,11 +224,15 @@ __global__ void kmc_pack_slab_kernel(const u64* __restrict__ hi, const u64* __re
 // The same slab straight from the LIVE table (no finalize, no sort -- a slab need not be ordered):
 // the first KMC_OCC_LIST_CAP claimed slots are listed in g.occ_list, so a small table is packed
 // without scanning it and without the host knowing its size.  Oversize when the table has more
-// keys than the slab (or than the list), when anything spilled, or when the host says so.
+// keys than the slab (or than the list), when anything spilled, when (k+16)-mer counts are pending, or when the host says so.
 template <int KW>
-__global__ void kmc_pack_slab_live_kernel(GTable g, u64 entries, int force_oversize, u64* __restrict__ slab) {
+__global__ void kmc_pack_slab_live_kernel(GTable g, const u64* __restrict__ sk_counters, u64 entries, int force_oversize, u64* __restrict__ slab) {
     const u64 n = g.counters[KMC_CTR_OCCUPIED];
-    const bool over = force_oversize || n > entries || n > g.occ_list_cap || g.counters[KMC_CTR_SPILL] != 0 || g.counters[KMC_CTR_ERR] != 0;
+    // (sk_counters: the (k+16)-mer table's, or null.  Counts pending there are not in the table yet: the host only queues their
+    // unfold when a poll has seen that table in use on this source -- if it guessed wrong, the slab says "oversize" and the
+    // table travels the other way, through kmc_finalize, which settles them)
+    const bool over = force_oversize || n > entries || n > g.occ_list_cap || g.counters[KMC_CTR_SPILL] != 0 || g.counters[KMC_CTR_ERR] != 0 ||
+                      (sk_counters && sk_counters[KMC_CTR_KMERS] != 0);
     const u64 i0 = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i0 < KMC_SLAB_HEADER) slab[i0] = i0 == 0 ? (over ? KMC_SLAB_OVERSIZE : n) : (i0 == 1 ? g.counters[KMC_CTR_KMERS] : 0ull);
     if (over) return;
