@@ -172,6 +172,25 @@ __device__ __forceinline__ bool stream_probe(StreamLds<KW>& L, u64 hi, u64 lo, b
     return ok && !hit;
 }
 
+// The same probe in two halves (one-word keys): issue = hash + the two home slots' loads, finish = compare + add.  The chunk
+// loop issues window j + 1 before it finishes window j, so that a wave has two probes' LDS reads in flight instead of
+// sitting out every read's latency (the straight-line version above was meant to overlap like that; the compiler put each
+// window's s_waitcnt right behind its own reads -- 29 instructions per window, yet 260 SIMD cycles: profiles/r03_stream_*).
+struct StreamProbe1 { u32 h; u64 k0, k1; };
+__device__ __forceinline__ StreamProbe1 stream_issue1(StreamLds<1>& L, u64 lo) {
+    StreamProbe1 p;
+    p.h = stream_home<1>(0, lo);
+    p.k0 = __hip_atomic_load(&L.slot[p.h].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    p.k1 = __hip_atomic_load(&L.slot[p.h + 1].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return p;
+}
+__device__ __forceinline__ bool stream_finish1(StreamLds<1>& L, const StreamProbe1& p, u64 lo, bool ok) {
+    const bool m0 = p.k0 == lo, m1 = p.k1 == lo;
+    const bool hit = ok && (m0 || m1);
+    atomicAdd(&L.cnt[p.h + (m0 ? 0u : 1u)], hit ? 1u : 0u);
+    return ok && !hit;
+}
+
 // wide bit masks for the validity smear: 64 bits cover the 48-base window of KW==1,
 // 128 bits the 80-base window of KW==2
 template <int KW> struct WMask;
@@ -357,6 +376,19 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                 {  // (no per-lane skip of lanes without a valid window: the drain inside needs the whole wave)
                     // forward keys are counted; the flush picks the strand
                     u32 missmask = 0;  // bit j: this lane's window j missed both home slots
+                    if constexpr (KW == 1) {
+                        auto window = [&](int j) { return ((u64)alignbit(X[2], X[1], 30 - 2 * j) << 32 | alignbit(X[1], X[0], 30 - 2 * j)) & mask_lo; };
+                        u64 cur = window(0);
+                        StreamProbe1 pc = stream_issue1(L, cur);
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) {
+                            u64 nxt = 0;
+                            StreamProbe1 pn = pc;
+                            if (j + 1 < 16) { nxt = window(j + 1); pn = stream_issue1(L, nxt); }
+                            missmask |= stream_finish1(L, pc, cur, !((inv16 >> j) & 1)) ? (1u << j) : 0u;
+                            cur = nxt; pc = pn;
+                        }
+                    } else {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) {
                         const int s = 30 - 2 * j;
@@ -368,6 +400,7 @@ void kmc_stream_kernel(const uint8_t* __restrict__ bases, u64 n_bases, const u64
                         if constexpr (KW == 2) fhi = ((u64)f[3] << 32 | f[2]) & mask_hi;
                         const bool ok = !((inv16 >> j) & 1);
                         missmask |= stream_probe<KW>(L, fhi, flo, ok) ? (1u << j) : 0u;
+                    }
                     }
                     {
                         nk += (u32)__popc(~inv16 & 0xFFFFu);

@@ -1,23 +1,34 @@
-"""The bench.py output contract, checked on the committed line of the last GPU run
-(profiles/r02_bench_n1.json; the strong-scaling rehearsal line next to it): the keys and types the driver and the judge read."""
+"""The bench.py output contract, checked on the committed lines of the last GPU runs (profiles/r03_bench_n1.json and the
+N > 1 rehearsal lines next to it): the keys and types the driver and the judge read."""
 import json
 import os
 
 from conftest import ROOT
 
 
+def _line(name):
+    return json.load(open(os.path.join(ROOT, "profiles", name)))
+
+
 def test_committed_bench_line_has_the_contract_keys():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_bench_n1.json")))
+    line = _line("r03_bench_n1.json")
     for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
                      ("ms_per_step", float), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict),
                      ("roofline", dict), ("cpu_baseline", dict)):
         assert key in line and isinstance(line[key], typ), key
     assert line["vs_baseline"] is None and line["scaling"] == "weak" and line["data"] == "synthetic" and line["higher_is_better"] is True
+    assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5          # the driver's command
     assert "workload" in line["config"] and "model" not in line["config"]
+    assert line["config"]["workload"].startswith("10 GB synthetic FASTA") and "seed 2" in line["config"]["workload"] and "k=31" in line["config"]["workload"]
     rf = line["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert rf["traffic"] is None or 0.9 < rf["traffic"] / rf["algorithmic_bytes_per_step"] < 1.2
+    assert abs(rf["achieved"] - rf["algorithmic_bytes_per_step"] / (rf["kernel_ms"] * 1e-3) / 1e9) / rf["achieved"] < 1e-3
+    # the nominal peak next to the rate a plain read-only kernel reached over the same bytes in the same run
+    assert rf["peak_measured"] > 5000 and abs(rf["frac_of_measured"] - rf["achieved"] / rf["peak_measured"]) < 2e-3
+    assert "kmc_read_peak_kernel" in rf["peak_measured_by"]["kernel"]
+    # traffic is either absent or says where it comes from (PMC passes are not part of a bench run)
+    assert rf["traffic"] is None or ("not measured in this run" in rf["traffic_source"] and 0.9 < rf["traffic"] / rf["algorithmic_bytes_per_step"] < 1.2)
     # value is whole-job throughput: k-mers of all steps / elapsed
     kmers = line["config"]["kmers_per_gpu"] * line["n_gpus"]
     assert abs(line["value"] - kmers / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
@@ -26,8 +37,25 @@ def test_committed_bench_line_has_the_contract_keys():
     assert line["config"]["exact_full_size_check"]["bit_exact"] is True   # the full-size table against the analytic oracle
 
 
-def test_strong_scaling_line_says_so():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r02_rehearsal_n2_strong_one_gpu_gloo.json")))
-    assert line["scaling"] == "strong" and line["n_gpus"] == 2
-    weak = json.load(open(os.path.join(ROOT, "profiles", "r02_rehearsal_n2_one_gpu_gloo.json")))
-    assert weak["scaling"] == "weak" and weak["n_gpus"] == 2
+def test_n_gt_1_default_is_config_4_strong_with_the_weak_figure_appended():
+    for n in (2, 3):
+        line = _line("r03_rehearsal_n%d_one_gpu_gloo.json" % n)
+        assert line["n_gpus"] == n and line["scaling"] == "strong" and line["cpu_baseline"] is None
+        w = line["config"]["workload"]
+        assert w.startswith("50 GB synthetic FASTA in total, records split over the ranks") and "seed 3" in w and "k=31" in w and ("%dxMI355X" % n) in w
+        assert line["config"]["kmers_all_gpus"] == line["config"]["reduced"]["kmers_all_owners"]      # every k-mer of every rank accounted for
+        assert line["config"]["exact_full_size_check"]["bit_exact"] is True
+        assert line["config"]["reduce_finalize_every"] == 5 and "every step" in line["config"]["every_step_delivers"]
+        assert abs(line["value"] - line["config"]["kmers_all_gpus"] / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+        wk = line["weak_scaling"]
+        assert wk["scaling"] == "weak" and wk["workload"].startswith("10 GB synthetic FASTA per GPU") and "seed 2" in wk["workload"]
+        assert wk["exact_full_size_check"]["bit_exact"] is True and wk["reduced"]["kmers_all_owners"] == wk["kmers_per_gpu"] * n
+        assert abs(wk["value"] - wk["kmers_per_gpu"] * n / (wk["ms_per_step"] * 1e-3)) / wk["value"] < 1e-3
+
+
+def test_sort_path_line_prices_its_own_pipeline():
+    line = _line("r03_bench_n1_pool0_1GB.json")
+    sp = line["roofline"]["sort_pipeline"]
+    assert line["config"]["algo"] == "sort" and sp["key_units_per_kmer"] == 8 and 0 < sp["frac"] < 1
+    n_bases, n_kmers = line["config"]["bases_per_gpu"], line["config"]["kmers_per_gpu"]
+    assert sp["model_bytes_per_step"] == (n_bases + 8 * n_kmers) * 8
