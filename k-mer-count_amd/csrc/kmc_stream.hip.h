@@ -175,7 +175,8 @@ __device__ __forceinline__ bool stream_probe(StreamLds<KW>& L, u64 hi, u64 lo, b
 // The same probe in two halves (one-word keys): issue = hash + the two home slots' loads, finish = compare + add.  The chunk
 // loop issues window j + 1 before it finishes window j, so that a wave has two probes' LDS reads in flight instead of
 // sitting out every read's latency (the straight-line version above was meant to overlap like that; the compiler put each
-// window's s_waitcnt right behind its own reads -- 29 instructions per window, yet 260 SIMD cycles: profiles/r03_stream_*).
+// window's s_waitcnt right behind its own reads -- 29 instructions per window, yet 260 SIMD cycles).  Measured: 16.9 -> 16.6 ms
+// on the benchmark batch; both home slots in ONE ds_read2_b64 instead of two ds_read_b64: 17.3 (profiles/r03_stream_variants.txt).
 struct StreamProbe1 { u32 h; u64 k0, k1; };
 __device__ __forceinline__ StreamProbe1 stream_issue1(StreamLds<1>& L, u64 lo) {
     StreamProbe1 p;
