@@ -173,12 +173,11 @@ int kmc_export(kmc_ctx* ctx, uint64_t* key_hi, uint64_t* key_lo, uint64_t* count
 
 /* Device pointers to the sorted table of the last kmc_finalize (owned by the ctx, valid until the
  * next finalize/reset/destroy).  d_key_hi is NULL when keys fit one word.
- * Ordering contract: when kmc_finalize returns, every entry of the view has been written and released to device
- * memory, so the arrays may be read from any stream, by a peer copy or by a collective without further
- * synchronisation.  (The large-table paths synchronise the ctx stream.  The small-table kernel tells the host itself:
- * each workgroup releases its entries before it draws its ticket, and the last ticket's workgroup writes the word
- * kmc_finalize waits on to pinned host memory -- the kernel may still be clearing table slots at that moment, which
- * only the ctx stream's later work cares about.) */
+ * Ordering contract: when kmc_export_device returns, every kernel that writes the view has FINISHED, so the arrays may
+ * be read from any stream, by a peer copy or by a collective without further synchronisation.  (kmc_finalize itself may
+ * return earlier than that for a small table: its kernel tells the host through pinned memory that the view and the
+ * counters are complete while it is still clearing table slots -- work queued on the ctx stream is ordered behind it
+ * anyway, and this call waits for the kernel's end, once, before it hands out pointers.) */
 int kmc_export_device(kmc_ctx* ctx, const void** d_key_hi, const void** d_key_lo,
                       const void** d_count, uint64_t* n_distinct);
 

@@ -134,6 +134,7 @@ struct kmc_ctx {
     // that were larger than this at the last finalize go there directly.  (KMC_FIN_SMALL_MAX overrides: the parity test of
     // the kernel's size boundaries runs it up to its limit, KMC_OCC_LIST_CAP.)
     u64 fin_small_max = 40000;
+    bool view_unsynced = false;   // the last small-table finalize was waited for through the mirror, not the stream (poll_fin)
     bool batch_pending = false;  // a COUNT kernel (unknown number of new keys) is queued since the last poll
     u64 unpolled_adds = 0;       // upper bound of keys added by merge kernels since the last poll
     bool walk_overflowed = false;  // the last WALK/STREAM launches counted >5% of their k-mers with global atomics
@@ -448,6 +449,7 @@ int poll_fin(kmc_ctx* c) {
             std::atomic_thread_fence(std::memory_order_acquire);
         }
         if (!seen) HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->view_unsynced = seen;   // (the kernel may still be running: kmc_export_device waits for its end before it hands out pointers)
     }
     c->st.n_async_ok = c->h_counters[KMC_CTR_FINOK];
     c->st.n_async_slabs_skipped = c->h_counters[KMC_CTR_FINSKIP];
@@ -1186,7 +1188,15 @@ int launch_sklog(kmc_ctx* c, const SkLog& lg, u32 wgrid) {
 // the prior of KMC_ALGO_AUTO's cost comparison until the ctx has sorted something itself
 #define KMC_SORT_MS_PER_BASE_1 2.9e-8
 #define KMC_SORT_MS_PER_BASE_2 5.0e-8
+int count_batch_device_body(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len);
 int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len) {
+    const int rc = count_batch_device_body(c, d_bases, d_offsets, n_reads, n_bases, max_read_len);
+    // the events of finished batches are read here, BEHIND this batch's launches (or in kmc_get_stats / kmc_poll): in front of
+    // them the microseconds would lie between a step's synchronisation and its successor's first launch
+    if (c->tb.size() >= 4) harvest_timing(c);
+    return rc;
+}
+int count_batch_device_body(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_reads, u64 n_bases, u64 max_read_len) {
     { int rc = resolve_async(c); if (rc) return rc; }
     { int rc = undrain(c); if (rc) return rc; }
     if (c->pending) { int rc = poll_and_settle(c); if (rc) return rc; }
@@ -1242,9 +1252,6 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
     }
     c->st.algo_last = algo;
 
-    // (the events of finished batches are read in kmc_get_stats / kmc_poll -- or here and in kmc_finalize once a few
-    //  have piled up: reading them costs microseconds of host time between a step's synchronisation and the next launch)
-    if (c->tb.size() >= 4) harvest_timing(c);
     c->tb.emplace_back();    // this batch's launch events
     c->tb.back().n_bases = n_bases;
     int rc = KMC_OK;
@@ -1274,7 +1281,12 @@ int count_batch_device(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets,
                 double opt = (double)freeslots / (4.0 * std::max(c->rho_last, 1e-9)) / (double)kmers_per_unit;
                 take = std::max<u64>(safe, (u64)std::min<double>(opt, (double)prev * 16.0));
             } else if (c->rho_hist >= 0.0) {
-                double opt = (double)freeslots / (8.0 * std::max(c->rho_hist, 1e-9)) / (double)kmers_per_unit;
+                // history says rho_hist new keys per k-mer.  A launch may bring 8 x that -- 3 x when the table is known to be
+                // empty: then "saving" it costs nothing, a whole batch of the same source brings what the last one brought
+                // (rho_hist is a whole-batch ratio), and a table with room for 3 x of it takes the batch in ONE launch
+                // (pool 100 of the cardinality sweep went out in four launches with a host poll behind each: 2.9 ms per GB)
+                const bool empty = occ == 0 && c->h_counters[KMC_CTR_SPILL] == 0 && !c->pending;
+                double opt = (double)freeslots / ((empty ? 3.0 : 8.0) * std::max(c->rho_hist, 1e-9)) / (double)kmers_per_unit;
                 take = std::max<u64>(safe, (u64)std::min<double>(opt, 1e18));
             }
             return std::min<u64>(take, units_left);
@@ -1837,7 +1849,6 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     rc = resolve_async(c);   // (a finalize queued by kmc_finalize_async: its view, when it produced one, is the result)
     if (rc) return rc;
     if (c->drained && c->sorted_valid) {  // nothing was added since the last finalize (which emptied the table into the view)
-        if (c->tb.size() >= 4) harvest_timing(c);
         if (n_distinct) *n_distinct = c->n_sorted;
         if (n_total) *n_total = c->st.n_kmers;
         return KMC_OK;
@@ -1854,6 +1865,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         rc = launch_small_finalize(c, fgrid_used);
         if (rc) return rc;
         tried_fast = true;
+        if (c->tb.size() >= 4) harvest_timing(c);   // (older batches' events, while the GPU is busy with this one)
     }
     rc = tried_fast ? poll_fin_and_settle(c) : poll_and_settle(c);
     if (!rc && c->acc_n) rc = flush_acc(c);  // (the poll may have recovered an overflow by extracting the rest of a batch)
@@ -1967,7 +1979,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     c->sorted_valid = true;
     c->st.n_distinct = n;
     c->st.n_kmers = n ? n_kmers : 0;
-    if (c->tb.size() >= 4) harvest_timing(c);
+    if (!fast_done && c->tb.size() >= 4) harvest_timing(c);
     if (n_distinct) *n_distinct = n;
     if (n_total) *n_total = c->st.n_kmers;
     return KMC_OK;
@@ -2021,6 +2033,11 @@ static int kmc_export_device_impl(kmc_ctx* c, const void** d_key_hi, const void*
     if (!c) return KMC_ERR_ARG;
     { int rc = resolve_async(c); if (rc) return rc; }
     if (!c->sorted_valid) return fail(c, KMC_ERR_STATE, "kmc_export_device before kmc_finalize");
+    if (c->view_unsynced) {   // (see poll_fin: the finalize kernel told the host it was done before it ended)
+        HIPCHK(c, hipSetDevice(c->cfg.device));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->view_unsynced = false;
+    }
     if (d_key_hi) *d_key_hi = c->KW == 2 ? c->v_hi : nullptr;
     if (d_key_lo) *d_key_lo = c->v_lo;
     if (d_count) *d_count = c->v_cnt;
@@ -2410,6 +2427,11 @@ static int count_file_pipeline(kmc_ctx** ctxs, uint32_t n_ctx, const char* path,
             rc = kmc_finalize(src, &nd, &nt);
             if (rc) { memcpy(c0->err, src->err, sizeof(c0->err)); return rc; }
             if (!nd) continue;
+            if (src->view_unsynced) {   // (its view is read on ANOTHER ctx's stream below: poll_fin, kmc_export_device)
+                HIPCHK(c0, hipSetDevice(src->cfg.device));
+                HIPCHK(c0, hipStreamSynchronize(src->stream));
+                src->view_unsynced = false;
+            }
             HIPCHK(c0, hipSetDevice(dst->cfg.device));
             const size_t nb = (size_t)nd * sizeof(u64);
             rc = ensure(dst, dst->rx_lo, nb); if (!rc) rc = ensure(dst, dst->rx_cnt, nb); if (!rc && dst->KW == 2) rc = ensure(dst, dst->rx_hi, nb);

@@ -37,7 +37,9 @@ __device__ __forceinline__ void sklog_unfold_one(const GTable& g, int k, u64 top
 // atomic per bin, then tile by tile (128 KB of records) groups the tile by bin in LDS and writes it out in that order, so
 // that consecutive lanes store consecutive records of one bin -- runs of 128 bytes instead of single records.
 // (Records stored straight from their lanes, 64 lanes into 64 different bins, took 19 ms per GB of reads for 0.45 GB of
-// records; profiles/r03_sklog_partition_variants.txt.)
+// records; profiles/r03_sklog_partition_variants.txt.  The bin histogram built by the walk kernel itself while it logs --
+// 4 KB of LDS counters, one-word keys only: the two-word kernel has none to spare -- saved 0.08-0.10 ms per GB at pools 50 and
+// 100 and cost the walk kernel 1 % on the benchmark input, whose steps never reach that code: not kept.)
 template <int W>
 __device__ __forceinline__ u32 sklog_bin_of(unsigned long long ax, unsigned long long ay, unsigned long long bx) {
     const u64 h = W == 4 ? kmc_hash_key<3>(bx, ax, ay) : kmc_hash_key<2>(ay, ax);

@@ -405,10 +405,14 @@ void kmc_small_finalize_kernel(GTable g, const u64* __restrict__ sk_counters, u3
             for (int w = 0; w < 16; ++w) tot += s_sum[w];
             __hip_atomic_store(&g.counters[KMC_CTR_SUM2], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // (release: the entries above are in memory before the ticket says so -- the host is told "view complete" by the
-        // last ticket's workgroup, possibly before this kernel has ended, and may hand the view to any stream then)
-        __threadfence();
-        if (tid == 0) s_last = (atomicAdd(ticket, 1u) == nb - 1) ? 1u : 0u;
+        // (No fence here.  The host is told "view complete" by the last ticket's workgroup, possibly before this kernel has
+        // ended: work queued on the ctx stream sees the entries in stream order; anybody else gets the pointers from
+        // kmc_export_device, which waits for the end of this kernel first -- a device-scope release in every one of the
+        // ~200 workgroups cost 10 us of a 16 us kernel.)
+        if (tid == 0) {
+            if (blockIdx.x == 0) __threadfence();   // (the sum above, read by the publishing workgroup, possibly on another XCD)
+            s_last = (atomicAdd(ticket, 1u) == nb - 1) ? 1u : 0u;
+        }
     }
     __syncthreads();
     if (!s_last) return;
