@@ -1934,7 +1934,14 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
         DevBuf* need[] = {&c->o_lo, &c->o_cnt, &c->t_lo, &c->t_cnt};
         for (DevBuf* b : need) { rc = ensure(c, *b, nb); if (rc) return rc; }
         if (c->KW == 2) { rc = ensure(c, c->o_hi, nb); if (rc) return rc; rc = ensure(c, c->t_hi, nb); if (rc) return rc; }
-        if (n_tab) {
+        if (n_tab && n_tab <= KMC_OCC_LIST_CAP && c->occ_list && c->h_counters[KMC_CTR_SPILL] == 0 && c->h_counters[KMC_CTR_ERR] == 0) {
+            // every claimed slot is listed (and its key kept in the dense key list): no scan of the table
+            GTable g = gtable_of(c, c->tab);
+            const int grid = grid_for(c, n_tab, 256);
+            if (c->KW == 1) hipLaunchKernelGGL(kmc_compact_list_kernel<1>, dim3(grid), dim3(256), 0, c->stream, g, n_tab, (u64*)nullptr, (u64*)c->t_lo.p, (u64*)c->t_cnt.p);
+            else hipLaunchKernelGGL(kmc_compact_list_kernel<2>, dim3(grid), dim3(256), 0, c->stream, g, n_tab, (u64*)c->t_hi.p, (u64*)c->t_lo.p, (u64*)c->t_cnt.p);
+            HIPCHK(c, hipGetLastError());
+        } else if (n_tab) {
             const int parity = c->fin_parity;
             c->fin_parity ^= 1;
             GTable g = gtable_of(c, c->tab);

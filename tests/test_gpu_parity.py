@@ -1137,9 +1137,9 @@ def test_planner_randomised_batch_sequences(kmc, oracle):
     reads and N bytes, under all four algorithms and k in {21, 31, 47, 48, 63} -- every look at the table must equal the
     oracle's count of everything added since the last reset, and the planner's debug invariant must hold (no risky
     launch armed on counters older than a queued unfold / merge: kmc_stats.n_planner_stale)."""
-    rng = np.random.default_rng(20261005)
+    rng = np.random.default_rng(int(os.environ.get("KMC_STRESS_SEED", "20261005")))   # (tools/r03_stress.sh runs other seeds)
     algos = [kmc.ALGO_AUTO, kmc.ALGO_WALK, kmc.ALGO_STREAM, kmc.ALGO_SORT]
-    n_cases = 36
+    n_cases = int(os.environ.get("KMC_STRESS_CASES", "36"))
     for case in range(n_cases):
         k = int(rng.choice([21, 31, 47, 48, 63]))
         algo = algos[case % 4]
@@ -1154,7 +1154,7 @@ def test_planner_randomised_batch_sequences(kmc, oracle):
         with kmc.KmerCounter(k=k, canonical=canonical, algo=algo) as kc:
             n_ops = int(rng.integers(2, 6))
             for op in range(n_ops):
-                pool = int(rng.choice([0, 10, 40, 1000]))
+                pool = int(rng.choice([0, 10, 40, 1000] if "KMC_STRESS_SEED" not in os.environ else [0, 10, 20, 40, 100, 1000]))
                 n_rec = int(rng.integers(200, 70_000 if algo != kmc.ALGO_STREAM else 25_000))
                 s = kmc.Synth(seed=int(rng.integers(1, 1 << 30)), pool=pool)
                 hb, ho = kmc.synth_reads_host(s, int(rng.integers(0, 1000)), n_rec)
@@ -1256,3 +1256,24 @@ def test_msd_sort_counted_spans(kmc, oracle):
     with kmc.KmerCounter(mode=kmc.MODE_LR) as kc:
         kc.add_batch(hb, ho)
         assert kc.export().equals(oracle.count_lr(hb, ho))
+
+
+def test_reference_mode_empty_and_short_reads(kmc, oracle):
+    """LR mode's pair kernel finds the read of a window start from one 64-ary search per workgroup plus 257 staged read
+    ends; more reads than that ending within a workgroup's 256 positions (runs of empty reads) take its general search.
+    Runs of 0 / 300 / 3000 empty reads between reads of 0..79 bases (no key) and 80..400 bases: the oracle's table."""
+    rng = np.random.default_rng(17)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    for n_empty in (0, 300, 3000):
+        lens = []
+        for _ in range(60):
+            lens.append(int(rng.integers(80, 401)))
+            lens.extend([0] * int(rng.integers(0, n_empty + 1)))
+            lens.append(int(rng.integers(0, 80)))
+        lens = np.array(lens, dtype=np.uint64)
+        ho = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64)
+        hb = acgt[rng.integers(0, 4, int(ho[-1]))].copy()
+        hb[300:900] = hb[1300:1900]          # repeated stretches: equal keys
+        with kmc.KmerCounter(mode=kmc.MODE_LR) as kc:
+            kc.add_batch(hb, ho)
+            assert kc.export().equals(oracle.count_lr(hb, ho)), n_empty

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 kmc = importlib.import_module("k-mer-count_amd")
 for k in (31, 63):
-    for n in (20_000, 1_000_000, 20_000_000):
+    for n in ([int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else (20_000, 1_000_000, 20_000_000)):
         rng = np.random.default_rng(n + k)
         lo = np.unique(rng.integers(0, 2**62, n, dtype=np.uint64))
         n = lo.size
