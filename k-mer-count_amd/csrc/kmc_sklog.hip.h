@@ -209,14 +209,22 @@ void kmc_sklog_consume_kernel(const u64* __restrict__ binned, const u32* __restr
     __syncthreads();
     constexpr u32 M = KMC_SKLOG_TCAP - 1;
     const u32 n_round = (n + 1023u) & ~1023u;
+    // (the next record of a thread is on its way while this one goes through the LDS table: the probing loop below is a chain
+    // of LDS round trips with nothing else in flight)
+    u64x2_t na = u64x2_t{0, 0};
+    u64 ntop = 0;
+    if (tid < n) {
+        const u64x2_t* r = reinterpret_cast<const u64x2_t*>(bin + (size_t)tid * W);
+        na = r[0];
+        if (W == 4) ntop = r[1].x;
+    }
     for (u32 i = tid; i < n_round; i += 1024) {
         const bool act = i < n;
-        u64 lo = 0, mid = 0, top = 0;
-        if (act) {
-            const u64x2_t* r = reinterpret_cast<const u64x2_t*>(bin + (size_t)i * W);
-            const u64x2_t a = r[0];
-            lo = a.x; mid = a.y;
-            if (W == 4) top = r[1].x;
+        const u64 lo = na.x, mid = na.y, top = ntop;
+        if (i + 1024 < n) {
+            const u64x2_t* r = reinterpret_cast<const u64x2_t*>(bin + (size_t)(i + 1024) * W);
+            na = r[0];
+            if (W == 4) ntop = r[1].x;
         }
         const u64 cw = W == 4 ? top : mid;   // the claimed word of this record
         u32 h = (u32)(kmc_mix64(lo ^ kmc_mix64(mid + 0x9E3779B97F4A7C15ull) ^ (top * 0xD6E8FEB86659FD93ull)) >> 20) & M;
