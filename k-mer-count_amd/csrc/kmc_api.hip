@@ -1177,7 +1177,7 @@ int launch_sklog(kmc_ctx* c, const SkLog& lg, u32 wgrid) {
         if (c->KW == 1) { if (canon) SKLOG_LAUNCH(1, true, 2); else SKLOG_LAUNCH(1, false, 2); }
         else { if (canon) SKLOG_LAUNCH(2, true, 2); else SKLOG_LAUNCH(2, false, 2); }
     } else {
-        if (canon) SKLOG_LAUNCH(2, true, 4); else SKLOG_LAUNCH(2, false, 4);
+        if (canon) SKLOG_LAUNCH(2, true, 3); else SKLOG_LAUNCH(2, false, 3);
     }
 #undef SKLOG_LAUNCH
     HIPCHK(c, hipGetLastError());
@@ -1450,7 +1450,7 @@ int count_batch_device_body(kmc_ctx* c, const uint8_t* d_bases, const u64* d_off
                 SkLog lg{};
                 const int wgrid = kmc_walk_grid(take, c->n_cu);
                 if (c->sklog_on && skt.key_lo && !getenv("KMC_NO_SKLOG")) {
-                    const u32 words = c->cfg.k > KMC_SK_MAX_K ? 4u : 2u;
+                    const u32 words = c->cfg.k > KMC_SK_MAX_K ? 3u : 2u;
                     const u64 steps_per_read = std::min<u64>(std::max<u64>(max_read_len, 1), KMC_WALK_MAX_READ) / KMC_WALK_STRIDE + 1;
                     u64 cap = ((take + wgrid - 1) / wgrid + 1) * 64ull * steps_per_read;
                     cap = std::min<u64>(cap, (12ull << 30) / ((u64)wgrid * words * sizeof(u64)));

@@ -43,9 +43,25 @@ __device__ __forceinline__ void sklog_unfold_one(const GTable& g, int k, u64 top
 // records; profiles/r03_sklog_partition_variants.txt.  The bin histogram built by the walk kernel itself while it logs --
 // 4 KB of LDS counters, one-word keys only: the two-word kernel has none to spare -- saved 0.08-0.10 ms per GB at pools 50 and
 // 100 and cost the walk kernel 1 % on the benchmark input, whose steps never reach that code: not kept.)
+// A record is W words: {lo, mid} (k <= 47) or {lo, mid, top} (k >= 48: 24 bytes -- a fourth, empty word made the records a
+// third larger on every pass over them).  Two-word records are 16-byte aligned and move as one dwordx4; three-word
+// records are 8-byte aligned: three dwordx2 (a wave still covers 1536 contiguous bytes).
+struct SkRec { u64 lo, mid, top; };
+template <int W>
+__device__ __forceinline__ SkRec sklog_load(const u64* __restrict__ p) {
+    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    if (W == 2) { const u64x2_t a = *reinterpret_cast<const u64x2_t*>(p); return SkRec{a.x, a.y, 0ull}; }
+    return SkRec{p[0], p[1], p[2]};
+}
+template <int W>
+__device__ __forceinline__ void sklog_store(u64* __restrict__ p, const SkRec& r) {
+    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+    if (W == 2) { *reinterpret_cast<u64x2_t*>(p) = u64x2_t{r.lo, r.mid}; return; }
+    p[0] = r.lo; p[1] = r.mid; p[2] = r.top;
+}
 template <int W>
 __device__ __forceinline__ u32 sklog_bin_of(unsigned long long ax, unsigned long long ay, unsigned long long bx) {
-    const u64 h = W == 4 ? kmc_hash_key<3>(bx, ax, ay) : kmc_hash_key<2>(ay, ax);
+    const u64 h = W == 3 ? kmc_hash_key<3>(bx, ax, ay) : kmc_hash_key<2>(ay, ax);
     return (u32)(h >> (64 - 10));
 }
 // exclusive prefix of the 1024 bin totals: every thread d of a 1024-thread workgroup gets off[d]; *total = their sum
@@ -67,22 +83,21 @@ template <int W>
 __global__ __launch_bounds__(1024)
 void kmc_sklog_hist_kernel(const u64* __restrict__ rec, const u32* __restrict__ count, u32 cap_wg, u32* __restrict__ span_hist, u32* __restrict__ bin_total) {
     __shared__ u32 cnt[KMC_SKLOG_BINS];
-    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
     const u32 w = blockIdx.x, tid = threadIdx.x;
     const u32 n = min(count[w], cap_wg);
     const u64* const span = rec + (size_t)w * cap_wg * W;
     cnt[tid] = 0;
     __syncthreads();
     for (u32 i0 = 0; i0 < n; i0 += 1024u * 4) {
-        u64x2_t a[4], b[4];
+        SkRec r[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const u32 i = i0 + tid + 1024u * u;
-            a[u] = u64x2_t{0, 0}; b[u] = u64x2_t{0, 0};
-            if (i < n) { const u64x2_t* r = reinterpret_cast<const u64x2_t*>(span + (size_t)i * W); a[u] = r[0]; if (W == 4) b[u] = r[1]; }
+            r[u] = SkRec{0, 0, 0};
+            if (i < n) r[u] = sklog_load<W>(span + (size_t)i * W);
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) if (i0 + tid + 1024u * u < n) atomicAdd(&cnt[sklog_bin_of<W>(a[u].x, a[u].y, b[u].x)], 1u);
+        for (int u = 0; u < 4; ++u) if (i0 + tid + 1024u * u < n) atomicAdd(&cnt[sklog_bin_of<W>(r[u].lo, r[u].mid, r[u].top)], 1u);
     }
     __syncthreads();
     const u32 c = cnt[tid];
@@ -92,9 +107,9 @@ void kmc_sklog_hist_kernel(const u64* __restrict__ rec, const u32* __restrict__ 
 
 template <int W> struct SklogPartLds {
     typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-    static constexpr int TILE = W == 2 ? 8192 : 4096;
+    static constexpr int TILE = W == 2 ? 8192 : 4096;   // 128 KB / 96 KB of records
     u64x2_t a[TILE];
-    u64x2_t b[W == 4 ? TILE : 1];
+    u64 t[W == 3 ? TILE : 1];    // third word of three-word records
     u32 cnt[KMC_SKLOG_BINS];     // records of the tile per bin, then their exclusive prefix
     u32 dst[KMC_SKLOG_BINS];     // record index (in the binned array) of the tile's first record of that bin, minus its LDS index
     u32 gpos[KMC_SKLOG_BINS];    // the span's running position in every bin (index in the binned array)
@@ -123,18 +138,16 @@ void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restri
         __syncthreads();   // (gpos written; the previous tile read out)
         L.cnt[tid] = 0;
         __syncthreads();
-        u64x2_t a[PER], b[PER];
+        SkRec rr[PER];
         u32 dr[PER];   // bin | rank within the tile << 10
 #pragma unroll
         for (int e = 0; e < PER; ++e) {
             const u32 i = tid + 1024u * e;
             dr[e] = ~0u;
-            a[e] = u64x2_t{0, 0}; b[e] = u64x2_t{0, 0};
+            rr[e] = SkRec{0, 0, 0};
             if (i < tn) {
-                const u64x2_t* r = reinterpret_cast<const u64x2_t*>(span + (size_t)(t0 + i) * W);
-                a[e] = r[0];
-                if (W == 4) b[e] = r[1];
-                const u32 d = sklog_bin_of<W>(a[e].x, a[e].y, b[e].x);
+                rr[e] = sklog_load<W>(span + (size_t)(t0 + i) * W);
+                const u32 d = sklog_bin_of<W>(rr[e].lo, rr[e].mid, rr[e].top);
                 dr[e] = d | (atomicAdd(&L.cnt[d], 1u) << 10);
             }
         }
@@ -158,8 +171,8 @@ void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restri
         for (int e = 0; e < PER; ++e) {
             if (dr[e] != ~0u) {
                 const u32 p = L.cnt[dr[e] & 1023u] + (dr[e] >> 10);
-                L.a[p] = a[e];
-                if (W == 4) L.b[p] = b[e];
+                L.a[p] = u64x2_t{rr[e].lo, rr[e].mid};
+                if (W == 3) L.t[p] = rr[e].top;
             }
         }
         __syncthreads();
@@ -168,12 +181,9 @@ void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restri
             const u32 p = tid + 1024u * e;
             if (p < tn) {
                 const u64x2_t ra = L.a[p];
-                u64x2_t rb = u64x2_t{0, 0};
-                if (W == 4) rb = L.b[p];
-                const u32 d = sklog_bin_of<W>(ra.x, ra.y, rb.x);
-                u64x2_t* o = reinterpret_cast<u64x2_t*>(binned + (size_t)(L.dst[d] + p) * W);
-                o[0] = ra;
-                if (W == 4) o[1] = rb;
+                const SkRec ro{ra.x, ra.y, W == 3 ? L.t[p] : 0ull};
+                const u32 d = sklog_bin_of<W>(ro.lo, ro.mid, ro.top);
+                sklog_store<W>(binned + (size_t)(L.dst[d] + p) * W, ro);
             }
         }
     }
@@ -182,7 +192,7 @@ void kmc_sklog_partition_kernel(const u64* __restrict__ rec, const u32* __restri
 template <int W> struct SklogTable {
     u64 lo[KMC_SKLOG_TCAP];
     u64 mid[KMC_SKLOG_TCAP];                 // W == 2: the claimed word (never all ones: a (k+16)-mer of k <= 47 leaves its top bits clear)
-    u64 top[W == 4 ? KMC_SKLOG_TCAP : 1];    // W == 4: the claimed word
+    u64 top[W == 3 ? KMC_SKLOG_TCAP : 1];    // W == 3: the claimed word
     u32 cnt[KMC_SKLOG_TCAP];
     u32 nfill;
 };
@@ -192,7 +202,6 @@ __global__ __launch_bounds__(1024)
 void kmc_sklog_consume_kernel(const u64* __restrict__ binned, const u32* __restrict__ bin_total, int k, GTable g) {
     extern __shared__ __align__(16) unsigned char sklog_smem[];
     SklogTable<W>& T = *reinterpret_cast<SklogTable<W>*>(sklog_smem);
-    typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
     __shared__ u32 s_wsum[16], s_begin;
     const u32 d = blockIdx.x, tid = threadIdx.x;
     const u32 n = bin_total[d];
@@ -206,7 +215,7 @@ void kmc_sklog_consume_kernel(const u64* __restrict__ binned, const u32* __restr
     const int kb = 2 * k;
     const u64 mask_lo = kb >= 64 ? ~0ull : ((1ull << kb) - 1);
     const u64 mask_hi = kb <= 64 ? 0ull : ((1ull << (kb - 64)) - 1);
-    u64* const claim = W == 4 ? T.top : T.mid;
+    u64* const claim = W == 3 ? T.top : T.mid;
     for (u32 i = tid; i < KMC_SKLOG_TCAP; i += 1024) { claim[i] = KMC_EMPTY64; T.cnt[i] = 0; }
     if (tid == 0) T.nfill = 0;
     __syncthreads();
@@ -214,28 +223,19 @@ void kmc_sklog_consume_kernel(const u64* __restrict__ binned, const u32* __restr
     const u32 n_round = (n + 1023u) & ~1023u;
     // (the next record of a thread is on its way while this one goes through the LDS table: the probing loop below is a chain
     // of LDS round trips with nothing else in flight)
-    u64x2_t na = u64x2_t{0, 0};
-    u64 ntop = 0;
-    if (tid < n) {
-        const u64x2_t* r = reinterpret_cast<const u64x2_t*>(bin + (size_t)tid * W);
-        na = r[0];
-        if (W == 4) ntop = r[1].x;
-    }
+    SkRec nr{0, 0, 0};
+    if (tid < n) nr = sklog_load<W>(bin + (size_t)tid * W);
     for (u32 i = tid; i < n_round; i += 1024) {
         const bool act = i < n;
-        const u64 lo = na.x, mid = na.y, top = ntop;
-        if (i + 1024 < n) {
-            const u64x2_t* r = reinterpret_cast<const u64x2_t*>(bin + (size_t)(i + 1024) * W);
-            na = r[0];
-            if (W == 4) ntop = r[1].x;
-        }
-        const u64 cw = W == 4 ? top : mid;   // the claimed word of this record
+        const u64 lo = nr.lo, mid = nr.mid, top = nr.top;
+        if (i + 1024 < n) nr = sklog_load<W>(bin + (size_t)(i + 1024) * W);
+        const u64 cw = W == 3 ? top : mid;   // the claimed word of this record
         // slot: the record's words folded to 32 bits, ONE 32-bit multiply (as kmc_stream.hip.h's home bucket; independent of the
         // bin, which is a 64-bit mix of the same words).  The first version mixed 64 bits twice -- five 64-bit multiplies, twenty
         // quarter-rate v_mul per record; measured difference: 1-2 % of the step.
         u32 fa = (u32)lo ^ __builtin_amdgcn_alignbit((u32)(lo >> 32), (u32)(lo >> 32), 21) ^ __builtin_amdgcn_alignbit((u32)mid, (u32)mid, 27) ^
                  __builtin_amdgcn_alignbit((u32)(mid >> 32), (u32)(mid >> 32), 13);
-        if (W == 4) fa ^= __builtin_amdgcn_alignbit((u32)top, (u32)top, 7) ^ __builtin_amdgcn_alignbit((u32)(top >> 32), (u32)(top >> 32), 17);
+        if (W == 3) fa ^= __builtin_amdgcn_alignbit((u32)top, (u32)top, 7) ^ __builtin_amdgcn_alignbit((u32)(top >> 32), (u32)(top >> 32), 17);
         u32 h = (((fa ^ (fa >> 15)) * 0x85EBCA6Bu) >> 20) & M;
         bool done = !act, direct = false;
         int probes = 0;
@@ -252,7 +252,7 @@ void kmc_sklog_consume_kernel(const u64* __restrict__ binned, const u32* __restr
                             const u64 old = atomicCAS((unsigned long long*)&claim[h], KMC_EMPTY64, KMC_LOCKED64);
                             if (old == KMC_EMPTY64) {
                                 __hip_atomic_store(&T.lo[h], lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if (W == 4) __hip_atomic_store(&T.mid[h], mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (W == 3) __hip_atomic_store(&T.mid[h], mid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 __hip_atomic_store(&claim[h], cw, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 atomicAdd(&T.nfill, 1u);
                                 atomicAdd(&T.cnt[h], 1u);
@@ -263,7 +263,7 @@ void kmc_sklog_consume_kernel(const u64* __restrict__ binned, const u32* __restr
                     } else if (cur == KMC_LOCKED64) {
                         // being published; examine it next trip
                     } else if (cur == cw && __hip_atomic_load(&T.lo[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == lo &&
-                               (W != 4 || __hip_atomic_load(&T.mid[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == mid)) {
+                               (W != 3 || __hip_atomic_load(&T.mid[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == mid)) {
                         atomicAdd(&T.cnt[h], 1u);
                         done = true;
                     } else { h = (h + 1) & M; probes++; }
@@ -281,7 +281,7 @@ void kmc_sklog_consume_kernel(const u64* __restrict__ binned, const u32* __restr
         const u32 s = it >> 4, j = it & 15u;
         if (claim[s] != KMC_EMPTY64) {
             const u64 c = T.cnt[s];
-            sklog_unfold_one<KW, CANON>(g, k, W == 4 ? T.top[s] : 0ull, T.mid[s], T.lo[s], j, c, mask_hi, mask_lo);
+            sklog_unfold_one<KW, CANON>(g, k, W == 3 ? T.top[s] : 0ull, T.mid[s], T.lo[s], j, c, mask_hi, mask_lo);
         }
     }
 }

@@ -289,7 +289,7 @@ struct SkLog {
     u64* rec;      // nullptr: no log; else spans of cap_wg records of `words` u64 each, workgroup b's span at b * cap_wg
     u32* count;    // count[b] = records workgroup b wrote
     u32 cap_wg;
-    u32 words;     // 2: {lo, mid} (k <= 47); 4: {lo, mid, top, 0} (k >= 48)
+    u32 words;     // 2: {lo, mid} (k <= 47); 3: {lo, mid, top} (k >= 48)
 };
 template <int KW>
 __device__ __forceinline__ void sk_add(WalkLds<KW>& L, const GTable& sk, const SkLog& lg, WCtx ctx, u32 label) {
@@ -301,9 +301,9 @@ __device__ __forceinline__ void sk_add(WalkLds<KW>& L, const GTable& sk, const S
         const u32 idx = atomicAdd(&L.logn, 1u);
         if (idx < lg.cap_wg) {
             typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-            u64x2_t* r = reinterpret_cast<u64x2_t*>(lg.rec + ((size_t)blockIdx.x * lg.cap_wg + idx) * lg.words);
-            r[0] = u64x2_t{lo, mid};
-            if (lg.words == 4) r[1] = u64x2_t{ctx.hi >> 32, 0ull};
+            u64* const rp = lg.rec + ((size_t)blockIdx.x * lg.cap_wg + idx) * lg.words;
+            if (lg.words == 2) *reinterpret_cast<u64x2_t*>(rp) = u64x2_t{lo, mid};
+            else { rp[0] = lo; rp[1] = mid; rp[2] = ctx.hi >> 32; }   // (24-byte records: 8-byte aligned)
             return;
         }
     }
