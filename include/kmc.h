@@ -196,7 +196,7 @@ uint32_t kmc_owner_of(uint64_t key_hi, uint64_t key_lo, uint32_t n_parts);
  * its size in 64-bit words for this ctx's key width.  kmc_pack_slab_device writes this ctx's table
  * into d_slab -- the sorted view after kmc_finalize, otherwise straight from the live table
  * (unsorted; no finalize and no host synchronisation needed first) -- or marks the slab "oversize"
- * when the table has more than slab_entries keys (live table: also more than 131072).  kmc_merge_slabs_device adds, from n_slabs consecutive slabs (the all-gather
+ * when the table has more than slab_entries keys (live table: also more than 1048576, the length of its list of claimed slots).  kmc_merge_slabs_device adds, from n_slabs consecutive slabs (the all-gather
  * result), every pair with kmc_owner_of(key, n_parts) == my_part; oversize slabs are skipped and
  * counted in kmc_stats.n_slabs_skipped at the next kmc_finalize (the caller then moves those
  * tables with kmc_partition_device + all-to-all + kmc_merge_pairs_device).  Both calls are

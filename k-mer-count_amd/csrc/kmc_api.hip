@@ -132,7 +132,7 @@ struct kmc_ctx {
     // The rank sort of kmc_small_finalize_kernel is quadratic: 16 us for 1 k keys, 0.24 ms for 24 k, 0.8 ms for 68 k (measured).  The
     // weighted radix sort that larger tables take costs 0.25-0.3 ms at that size (a dozen small launches, two polls): tables
     // that were larger than this at the last finalize go there directly.  (KMC_FIN_SMALL_MAX overrides: the parity test of
-    // the kernel's size boundaries runs it up to its limit, KMC_OCC_LIST_CAP.)
+    // the kernel's size boundaries runs it up to its limit, KMC_FIN_KERNEL_MAX.)
     u64 fin_small_max = 40000;
     bool view_unsynced = false;   // the last small-table finalize was waited for through the mirror, not the stream (poll_fin)
     bool batch_pending = false;  // a COUNT kernel (unknown number of new keys) is queued since the last poll
@@ -580,7 +580,7 @@ int poll_fin_and_settle(kmc_ctx* c) {
 // workgroups.  (Workgroups past the table leave at once, but hundreds of them still cost microseconds.)  A table that
 // outgrew the grid is noticed by kmc_finalize and finalized again with the full grid.
 int small_finalize_grid(const kmc_ctx* c) {
-    return (int)std::min<u64>(KMC_OCC_LIST_CAP / KMC_FIN_CHUNK, std::max<u64>(64, (c->fin_hint + c->fin_hint / 4) / KMC_FIN_CHUNK + 8));
+    return (int)std::min<u64>(KMC_FIN_KERNEL_MAX / KMC_FIN_CHUNK, std::max<u64>(64, (c->fin_hint + c->fin_hint / 4) / KMC_FIN_CHUNK + 8));
 }
 // The speculative small-table finalize (kmc_table.hip.h): queued behind whatever is still running.
 int launch_small_finalize(kmc_ctx* c, int grid) {
@@ -1012,8 +1012,8 @@ bool arm_risky(kmc_ctx* c, const uint8_t* d_bases, const u64* d_offsets, u64 n_r
     } else if (occ <= KMC_OCC_LIST_CAP && c->occ_list && c->h_counters[KMC_CTR_SPILL] == 0) {
         const size_t nb = (size_t)KMC_OCC_LIST_CAP * sizeof(u64);
         if (ensure(c, c->snap_lo, nb) || ensure(c, c->snap_cnt, nb) || ensure(c, c->snap_n, 64) || (c->KW == 2 && ensure(c, c->snap_hi, nb))) return false;
-        if (c->KW == 1) hipLaunchKernelGGL(kmc_snapshot_kernel<1>, dim3(32), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->snap_lo.p, (u64*)c->snap_cnt.p, (u64*)c->snap_n.p);
-        else hipLaunchKernelGGL(kmc_snapshot_kernel<2>, dim3(32), dim3(256), 0, c->stream, g, (u64*)c->snap_hi.p, (u64*)c->snap_lo.p, (u64*)c->snap_cnt.p, (u64*)c->snap_n.p);
+        if (c->KW == 1) hipLaunchKernelGGL(kmc_snapshot_kernel<1>, dim3(occ > 32768 ? 256 : 32), dim3(256), 0, c->stream, g, (u64*)nullptr, (u64*)c->snap_lo.p, (u64*)c->snap_cnt.p, (u64*)c->snap_n.p);
+        else hipLaunchKernelGGL(kmc_snapshot_kernel<2>, dim3(occ > 32768 ? 256 : 32), dim3(256), 0, c->stream, g, (u64*)c->snap_hi.p, (u64*)c->snap_lo.p, (u64*)c->snap_cnt.p, (u64*)c->snap_n.p);
         if (hipGetLastError() != hipSuccess) return false;
         r.mode = 1;
     } else if (c->tab.cap <= (16ull << 20)) {
@@ -1682,7 +1682,7 @@ static int kmc_create_impl(kmc_ctx** out, const kmc_config* cfg) {
     c->cfg = *cfg;
     if (cfg->mode == KMC_MODE_LR) { c->KW = 2; c->klen = 54; c->cfg.k = 54; c->cfg.canonical = 0; }
     else { c->KW = cfg->k <= 31 ? 1 : 2; c->klen = cfg->k; }
-    if (const char* e = getenv("KMC_FIN_SMALL_MAX")) c->fin_small_max = std::min<u64>(strtoull(e, nullptr, 10), KMC_OCC_LIST_CAP);
+    if (const char* e = getenv("KMC_FIN_SMALL_MAX")) c->fin_small_max = std::min<u64>(strtoull(e, nullptr, 10), KMC_FIN_KERNEL_MAX);
     int rc = KMC_OK;
     auto body = [&]() -> int {
         HIPCHK(c, hipSetDevice(cfg->device));
@@ -1857,7 +1857,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     if (rc) return rc;
     if (c->runs.empty() && c->fin_hint <= c->fin_small_max) {
         // speculative small-table finalize, queued behind whatever is still running
-        const size_t fb = (size_t)KMC_OCC_LIST_CAP * sizeof(u64);
+        const size_t fb = (size_t)KMC_FIN_KERNEL_MAX * sizeof(u64);
         rc = ensure(c, c->o_lo, fb); if (rc) return rc;
         rc = ensure(c, c->o_cnt, fb); if (rc) return rc;
         if (c->KW == 2) { rc = ensure(c, c->o_hi, fb); if (rc) return rc; }
@@ -1880,7 +1880,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
             // the second finalize kernel sees the (k+16)-mer table empty again and may drain)
             bool again = false;
             if (tried_fast && c->runs.empty()) {
-                fgrid_used = KMC_OCC_LIST_CAP / KMC_FIN_CHUNK;
+                fgrid_used = (int)(std::min<u64>(c->fin_small_max + c->fin_small_max / 4, KMC_FIN_KERNEL_MAX) / KMC_FIN_CHUNK + 8);
                 rc = launch_small_finalize(c, fgrid_used);
                 if (rc) return rc;
                 again = true;
@@ -1894,7 +1894,7 @@ static int kmc_finalize_impl(kmc_ctx* c, uint64_t* n_distinct, uint64_t* n_total
     if (tried_fast && c->runs.empty() && c->h_counters[KMC_CTR_FASTFIN] != 1 && c->h_counters[KMC_CTR_SPILL] == 0 &&
         c->h_counters[KMC_CTR_OCCUPIED] > (u64)fgrid_used * KMC_FIN_CHUNK && c->h_counters[KMC_CTR_OCCUPIED] <= c->fin_small_max) {
         // the table outgrew the speculative grid (first finalize of a larger source): once more, full grid
-        fgrid_used = KMC_OCC_LIST_CAP / KMC_FIN_CHUNK;
+        fgrid_used = (int)(std::min<u64>(c->fin_small_max + c->fin_small_max / 4, KMC_FIN_KERNEL_MAX) / KMC_FIN_CHUNK + 8);
         rc = launch_small_finalize(c, fgrid_used);
         if (rc) return rc;
         rc = poll_fin_and_settle(c);
@@ -2000,7 +2000,7 @@ static int kmc_finalize_async_impl(kmc_ctx* c) {
     HIPCHK(c, hipSetDevice(c->cfg.device));
     if (c->async_fin || (c->drained && c->sorted_valid)) return KMC_OK;   // (queued already / final already)
     if (!c->runs.empty() || c->acc_n) return kmc_finalize(c, nullptr, nullptr);
-    const size_t fb = (size_t)KMC_OCC_LIST_CAP * sizeof(u64);
+    const size_t fb = (size_t)KMC_FIN_KERNEL_MAX * sizeof(u64);
     int rc = ensure(c, c->o_lo, fb); if (rc) return rc;
     rc = ensure(c, c->o_cnt, fb); if (rc) return rc;
     if (c->KW == 2) { rc = ensure(c, c->o_hi, fb); if (rc) return rc; }

@@ -53,7 +53,11 @@ struct GTable {
 // 131072: the rank-sort finalize costs n^2 / 64 compares per workgroup-of-16-keys -- 0.13 ms at 67 k keys, about what the
 // general path (compaction + weighted radix sort: 0.8 ms of fixed cost) takes at 131 k -- and the plateau inputs of the
 // cardinality sweep (pools of 32..100 lines: 29 k .. 255 k distinct 31-mers) sit right above the old limit
-#define KMC_OCC_LIST_CAP 131072
+// (Later in round 3 the two meanings were separated: the LIST -- claimed slots + their keys, 24 bytes per entry -- covers a
+// million keys, so that finalize compaction, reset and cheap snapshots go through it for every table of the cardinality sweep
+// up to pool 100 (572 k distinct 63-mers) instead of scanning millions of slots; the rank-sort KERNEL keeps its 131072.)
+#define KMC_OCC_LIST_CAP 1048576
+#define KMC_FIN_KERNEL_MAX 131072   // most keys kmc_small_finalize_kernel takes (its grid, its output buffers)
 
 __device__ __forceinline__ u64 kmc_mix64(u64 z) {
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;

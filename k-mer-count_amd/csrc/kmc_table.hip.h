@@ -278,7 +278,7 @@ __global__ void kmc_merge_slabs_kernel(GTable g, const u64* __restrict__ slabs, 
 }
 
 
-// Fast finalize for small tables (n <= KMC_OCC_LIST_CAP claimed slots, listed in g.occ_list): the GPU
+// Fast finalize for small tables (n <= KMC_FIN_KERNEL_MAX claimed slots, listed in g.occ_list): the GPU
 // form of the reference's final ordering step (k-mer-count/src/main.rs:87) for the common case of a
 // few thousand distinct keys, in ONE launch that uses the whole chip instead of one CU:
 //   rank sort -- keys in a table are distinct, so the sorted position of key i is the number of keys
@@ -322,7 +322,7 @@ void kmc_small_finalize_kernel(GTable g, const u64* __restrict__ sk_counters, u3
     __shared__ u64 s_sum[16];
     const u32 tid = threadIdx.x;
     const u64 n = g.counters[KMC_CTR_OCCUPIED];
-    const bool ok = n > 0 && n <= KMC_OCC_LIST_CAP && n <= g.occ_list_cap && n <= (u64)gridDim.x * KMC_FIN_CHUNK &&
+    const bool ok = n > 0 && n <= KMC_FIN_KERNEL_MAX && n <= g.occ_list_cap && n <= (u64)gridDim.x * KMC_FIN_CHUNK &&
                     g.counters[KMC_CTR_SPILL] == 0 && g.counters[KMC_CTR_ERR] == 0 &&
                     sk_counters[KMC_CTR_KMERS] == 0;   // (no counts pending in the (k+16)-mer table; its keys stay across launches)
     // (every workgroup that takes part reads these counters before it draws its ticket, and they change only
