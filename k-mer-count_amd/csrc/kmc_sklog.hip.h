@@ -222,7 +222,7 @@ void kmc_sklog_consume_kernel(const u64* __restrict__ binned, const u32* __restr
     constexpr u32 M = KMC_SKLOG_TCAP - 1;
     const u32 n_round = (n + 1023u) & ~1023u;
     // (the next record of a thread is on its way while this one goes through the LDS table: the probing loop below is a chain
-    // of LDS round trips with nothing else in flight)
+    // of LDS round trips with nothing else in flight.  Four or eight records ahead instead of one: no difference)
     SkRec nr{0, 0, 0};
     if (tid < n) nr = sklog_load<W>(bin + (size_t)tid * W);
     for (u32 i = tid; i < n_round; i += 1024) {
