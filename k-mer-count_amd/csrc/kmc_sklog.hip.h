@@ -18,8 +18,7 @@
 #define KMC_SKLOG_BINS 1024
 #define KMC_SKLOG_TCAP 4096      // LDS table slots of a consume workgroup (80 / 112 KB: one workgroup per CU.  Tables of 2048 slots -- two
                                  // workgroups per CU -- were measured on the plateau inputs: no faster, 2.16 / 2.20 / 2.44 vs 2.18 / 2.20 / 2.42 ms at k=31,
-                                 // 3.01 / 3.41 vs 3.09 / 3.44 at k=63: the kernel is bound by same-address LDS atomics of heavily repeated records,
-                                 // not by occupancy)
+                                 // 3.01 / 3.41 vs 3.09 / 3.44 at k=63: occupancy is not what bounds the kernel)
 
 // the 16 k-mers of one (k+16)-mer {top, mid, lo}, each + cnt (what kmc_sk_unfold_kernel does per table entry)
 template <int KW, bool CANON>
