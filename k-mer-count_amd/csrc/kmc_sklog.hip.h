@@ -239,7 +239,22 @@ void kmc_sklog_consume_kernel(const u64* __restrict__ binned, const u32* __restr
         bool done = !act, direct = false;
         int probes = 0;
         u32 trips = 0;
-        // one loop whose only back-edge is taken on a wave-uniform ballot (kmc_device.hip.h, gtable_add: why)
+        // HOT PATH, straight-line (the plateau inputs repeat every record thousands of times, so nearly every record finds
+        // itself in its home slot): the slot's words are read in the order they are published in reverse -- claim word first;
+        // LDS executes a wave's accesses in order, so words read behind a published claim word are the published ones --
+        // and the count goes up by one on a hit, by zero otherwise: no branch, no loop.  (Before, every record went through
+        // the probing loop below, whose back-edge is a wave-wide ballot: more scalar than vector instructions, PMC.)
+        {
+            const u64 c0 = __hip_atomic_load(&claim[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            asm volatile("" ::: "memory");   // (program order = issue order: the key words are read behind the claim word)
+            const u64 l0 = __hip_atomic_load(&T.lo[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const u64 m0 = W == 3 ? __hip_atomic_load(&T.mid[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : mid;
+            const bool hit = act && c0 == cw && c0 != KMC_EMPTY64 && c0 != KMC_LOCKED64 && l0 == lo && m0 == mid;
+            atomicAdd(&T.cnt[h], hit ? 1u : 0u);
+            done = done || hit;
+        }
+        // first sight of a record, a slot being published, a collision: the probing insert.  One loop whose only back-edge is
+        // taken on a wave-uniform ballot (kmc_device.hip.h, gtable_add: why)
         while (__builtin_amdgcn_ballot_w64(!done) != 0) {
             if (!done) {
                 if (probes >= 24 || ++trips > (1u << 20)) { direct = true; done = true; }
